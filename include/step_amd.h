@@ -1,0 +1,217 @@
+/* step_amd.h -- C ABI of libstep_amd.so: the MI355X (gfx950) kernels behind STeP's
+ * DAPS measurement-consistency path.
+ *
+ * The reference (zhangbingliang2019/STeP) is pure Python/PyTorch and has no FFI of
+ * its own; each entry point below names the reference code (file:line under the
+ * reference root) whose torch-op sequence it replaces.  The Python host layer
+ * (step_amd/forward_operator, step_amd/sampler) mirrors the reference's
+ * operator/sampler interface on top of exactly these symbols via ctypes.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer (tensor.data_ptr()) unless the
+ *     parameter comment says "host"; the caller owns every buffer;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every launch is asynchronous on it; no entry point allocates, frees or synchronises;
+ *   - return value: 0 = ok, negative = error (STEP_E_*); step_last_error() returns a
+ *     thread-local message; no C++ exception crosses this boundary;
+ *   - float data is IEEE fp32; complex data is interleaved (re, im) fp32 = torch.complex64;
+ *   - video tensors are contiguous [B][T][C][H][W].
+ */
+#ifndef STEP_AMD_H
+#define STEP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEP_OK            0
+#define STEP_E_INVALID    -1   /* bad argument / unsupported shape (nothing launched) */
+#define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
+
+const char* step_last_error(void);
+int         step_abi_version(void);
+
+/* ------------------------------------------------------------------ host-side tables */
+
+/* Closure index construction, reference forward_operator/blackhole.py:235-264.
+ * Visibility rows i = 0..n_rows-1 carry (row_time[i], row_t1[i], row_t2[i]) (station ids);
+ * a later row with the same key overwrites an earlier one (dict semantics).  Triangle
+ * (a,b,c) -> rows of (a,b),(b,c),(c,a); quadrangle (a,b,c,d) -> rows of (a,b),(c,d),(a,d),(b,c);
+ * conj = 1 where the row is stored with the stations swapped.  All pointers HOST.
+ * Outputs int64 [n_tri][3] x2 and [n_quad][4] x2 (the reference's torch.long tensors).
+ * A key with no row -> STEP_E_INVALID (the reference raises KeyError). */
+int bh_build_closure_tables(const double* row_time, const int32_t* row_t1, const int32_t* row_t2,
+                            int64_t n_rows,
+                            const double* tri_time, const int32_t* tri_sites, int64_t n_tri,
+                            const double* quad_time, const int32_t* quad_sites, int64_t n_quad,
+                            int64_t* cp_index, int64_t* cp_conj,
+                            int64_t* camp_index, int64_t* camp_conj);
+
+/* Transposed (baseline -> incident closures) tables used by the adjoint gather so that
+ * the scatter of Appendix-B items 2-3 is a deterministic gather.  All pointers HOST.
+ * ptr arrays have n_vis+1 entries; ent arrays 3*n_tri / 4*n_quad entries, each
+ * (k << 3) | (leg << 1) | conj.  Index out of [0,n_vis) -> STEP_E_INVALID. */
+int bh_build_incidence(const int64_t* cp_index, const int64_t* cp_conj, int64_t n_tri,
+                       const int64_t* camp_index, const int64_t* camp_conj, int64_t n_quad,
+                       int64_t n_vis,
+                       int32_t* cp_ptr, int32_t* cp_ent, int32_t* ca_ptr, int32_t* ca_ent);
+
+/* k-space row mask, reference forward_operator/dynamic_mri.py:9-39.
+ * mode 0 = same_mask (mask_frames = 1), 1 = split_mask, 2 = random_split_mask
+ * (np.random.seed(42) + np.random.shuffle restated: MT19937 + masked rejection sampling).
+ * mask: HOST float[mask_frames][resolution] of 0/1. */
+int mri_build_mask(int acc_factor, int mode, int resolution, int frames, int num_acs_lines,
+                   float* mask);
+
+/* ------------------------------------------------------------------ black-hole DFT, dense A */
+
+/* Rows per frame of the packed real matrix: 2F+1 (Re rows, Im rows, flux row of ones)
+ * rounded up to a multiple of 32. */
+int    bh_dense_rows_padded(int F);
+size_t bh_dense_packed_floats(int T, int F, int HW);           /* per packed copy */
+size_t bh_dense_fwd_workspace_floats(int T, int F, int HW, int B);
+
+/* Repack A_vis (complex64 [T][F][HW], the reference attribute blackhole.py:155) once at
+ * operator construction into the two fp32 images the kernels stream:
+ * a_frag (MFMA-fragment order, forward) and a_rows (row-planar [T][RP][HW], adjoint). */
+int bh_dense_pack(const void* A_vis_c64, int T, int F, int HW,
+                  float* a_frag, float* a_rows, void* stream);
+
+/* vis[b][t*F+f] = sum_n A[t][f][n] * x'[b][t][n], flux[b][t] = sum_n x'[b][t][n] with
+ * x' = max(x*scale+shift, clip_min) (clip_min = -inf -> no clip).
+ * Replaces forward_vis blackhole.py:315-321 (+ unnormalize :720-722, forward_flux :328-329,
+ * the clip of evaluate_chisq :672).  HW % 8 == 0. */
+int bh_dft_fwd_dense(const float* a_frag, int T, int F, int HW,
+                     const float* x, int B, float scale, float shift, float clip_min,
+                     float* vis_c64, float* flux, float* workspace, void* stream);
+
+/* grad[b][t][n] = out_scale * chain_scale[b] * ( sum_f Re(conj(A[t][f][n]) gvis[b][t*F+f])
+ *                                               + gflux[b][t] ).
+ * The autograd backward of forward_vis/forward_flux.
+ * chain_scale may be NULL (=1).  HW % 32 == 0. */
+int bh_dft_adj_dense(const float* a_rows, int T, int F, int HW,
+                     const float* gvis_c64, const float* gflux, const float* chain_scale,
+                     int B, float out_scale, float* grad, void* stream);
+
+/* ------------------------------------------------------------------ black-hole DFT, separable
+ * A[t][f][y*W+x] = ey[t][f][y] * ex[t][f][x] (what ehtim's ftmatrix produces: pulse * e^{2 pi i y v}
+ * * e^{2 pi i x u}); never materialises A.  Tables (fp32, built by the host layer):
+ *   ey_t  [T][H][64]     LDS image for the forward: col f = Re ey, col 32+f = Im ey, f = F is the
+ *                        flux row (1 + 0i), other cols 0
+ *   ey_ri [T][2][32][H]  planar Re / Im of ey (same row convention)
+ *   ex_ri [T][2][32][W]  planar Re / Im of ex (flux row = 1 + 0i)
+ * Requires F <= 31, H % 32 == 0, W % 32 == 0, H <= 512. */
+int bh_dft_fwd_sep(const float* ey_t, const float* ex_ri, int T, int F, int H, int W,
+                   const float* x, int B, float scale, float shift, float clip_min,
+                   float* vis_c64, float* flux, void* stream);
+int bh_dft_adj_sep(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
+                   const float* gvis_c64, const float* gflux, const float* chain_scale,
+                   int B, float out_scale, float* grad, void* stream);
+
+/* ------------------------------------------------------------------ closure quantities */
+
+typedef struct {
+    int32_t n_vis;            /* T*F */
+    int32_t n_tri, n_quad;    /* K_cp, K_ca */
+    int32_t T;                /* frames (flux length) */
+    const int32_t* cp_index;  /* [n_tri][3]  */
+    const int32_t* cp_conj;   /* [n_tri][3]  0/1 */
+    const int32_t* camp_index;/* [n_quad][4] */
+    const int32_t* cp_ptr;    /* incidence, see bh_build_incidence */
+    const int32_t* cp_ent;
+    const int32_t* ca_ptr;
+    const int32_t* ca_ent;
+} bh_tables_t;
+
+typedef struct {               /* a measurement (BlackHoleObservation, blackhole.py:23-132) */
+    const float* vis_c64;      /* [By][n_vis] complex   (may be NULL when w_vis == 0)  */
+    const float* sigma_vis;    /* [By][n_vis]                                         */
+    const float* amp;          /* [By][n_vis]           (may be NULL when w_amp == 0)  */
+    const float* sigma_amp;
+    const float* cphase;       /* [By][n_tri]  radians                                */
+    const float* sigma_cphase;
+    const float* logcamp;      /* [By][n_quad]                                        */
+    const float* sigma_logcamp;
+    const float* flux;         /* [By][T]                                             */
+    int32_t batch;             /* By: 1 (broadcast over chains) or B                  */
+} bh_meas_t;
+
+typedef struct {               /* blackhole.py:175-180 (weights already multiplied by their dims) */
+    float w_vis, w_amp, w_cp, w_camp, w_flux;
+    int32_t normalize;         /* loss_normalize */
+} bh_weights_t;
+
+/* Per-chain loss and its gradient w.r.t. vis / flux, from vis and flux of x01.
+ * Replaces chi2_* blackhole.py:448-491, normalize_chisq :665-669, the weighted sum of
+ * loss :736-771 and the autograd backward of all of it (Appendix B items 2-5).
+ *   loss [B]; chi2 [B][5] raw (vis, amp, cphase, logcamp, flux; 0 where weight == 0);
+ *   gvis [B][n_vis] complex = dL/dRe + i dL/dIm; gflux [B][T].  gvis/gflux may be NULL
+ *   (forward only, e.g. Metropolis-Hastings sample_MH daps.py:157-158). */
+int bh_closure_loss(const float* vis_c64, const float* flux, int B,
+                    const bh_tables_t* tab, const bh_meas_t* y, const bh_weights_t* w,
+                    float* loss, float* chi2, float* gvis_c64, float* gflux, void* stream);
+
+/* chi^2 of every data product for the evaluator (evaluate_chisq blackhole.py:671-699):
+ * vis_scale[b][t] (may be NULL) multiplies frame t's visibilities first (the per-frame flux
+ * alignment y_flux/x_flux is linear in the DFT).  chi2 [B][4] = vis, amp, cphase, logcamp, raw. */
+int bh_closure_chisq(const float* vis_c64, const float* vis_scale, int B, int F,
+                     const bh_tables_t* tab, const bh_meas_t* y, float* chi2, void* stream);
+
+/* Full observation from vis (forward_from_vis blackhole.py:393-401): amp, sigma_amp
+ * (= sigma broadcast), cphase, sigma_cphase, logcamp, sigma_logcamp.  sigma [n_vis]. */
+int bh_closure_observe(const float* vis_c64, const float* sigma, int B, const bh_tables_t* tab,
+                       float* amp, float* sigma_amp, float* cphase, float* sigma_cphase,
+                       float* logcamp, float* sigma_logcamp, void* stream);
+
+/* ------------------------------------------------------------------ dynamic MRI
+ * x, y, out: [B][T][2][R][R] fp32 (channel 0 = Re, 1 = Im); R == 192.
+ * rows: int32 [mask_frames][R] = kept k_y rows of each mask frame, ascending, padded with -1;
+ * nrows: int32 [mask_frames]; mask_frames = 1 (same_mask) or T; max_rows = max(nrows) (host
+ * knowledge; sizes the LDS row buffer, masks with more than 64 kept rows run in groups). */
+
+/* out = M * FFT2(fftshift(x_re + i x_im)), unnormalised (dynamic_mri.py:42-48). */
+int mri_forward(const float* x, int B, int T, int R, const int32_t* rows, const int32_t* nrows,
+                int mask_frames, int max_rows, float* out, void* stream);
+
+/* out = A^H g = ifftshift(R^2 IFFT2(M * g)): the vector-Jacobian product of mri_forward, i.e.
+ * what torch autograd computes for dynamic_mri.py:42-48 when a caller differentiates A(x). */
+int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const int32_t* nrows,
+                int mask_frames, int max_rows, float* out, void* stream);
+
+/* loss[b] = sum |A(x) - y|^2 over every k-space entry (base.py:40-41);
+ * grad = chain_scale[b] * d loss[b] / d x  (autograd of the above; Appendix B "MRI").
+ * grad may be NULL (loss only).  chain_scale may be NULL (=1).
+ * loss_part: workspace float[B*T] (per-frame partial losses); loss [B]. */
+int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
+                  const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
+                  const float* chain_scale, float* loss_part, float* loss, float* grad,
+                  void* stream);
+
+/* ------------------------------------------------------------------ MCMC state update */
+
+typedef struct {
+    float inv_tau2;      /* 1/tau^2            daps.py:101 */
+    float inv_sigma2;    /* 1/sigma^2          daps.py:102 */
+    float lr;            /* get_lr(ratio)      daps.py:233-239 */
+    float sqrt_lr;       /* np.sqrt(lr)        daps.py:139 */
+    float sqrt_2lr;      /* np.sqrt(2 lr)      daps.py:137 */
+    float momentum;      /* daps.py:140 */
+    float noise_scale;   /* np.sqrt(2 (1 - momentum)) */
+    int32_t algo;        /* 0 = langevin, 1 = hmc */
+} mcmc_params_t;
+
+/* score = -grad*inv_tau2 + (xt - x)*inv_sigma2 + prior  (score_fn daps.py:93-104), then
+ * mc_update daps.py:135-144 in place on x (and velocity for hmc).  Sets *nan_flag (int32,
+ * device) to 1 if any updated x is NaN (the guard of daps.py:202-203 without a per-step sync
+ * unless the host chooses to read it). */
+int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, const float* prior,
+                const float* eps, int64_t n, const mcmc_params_t* p, int32_t* nan_flag,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEP_AMD_H */

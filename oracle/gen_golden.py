@@ -187,9 +187,18 @@ def gen_bh_case(fo, LatentWrapper, name, n_sites, imsize, B, seed, weights, full
         out.update(A_vis=op.A_vis[0], x_gt=x_gt, x=x, x_near=x_near)
     out.update(obs_arrays("y_", y))
 
+    # fp64 evaluation of the same formulas: the yardstick where fp32 itself is noise-limited
+    orc64 = BlackholeOracle(op.A_vis.to(torch.complex128), op.sigma.double(), op.cp_index,
+                            op.cp_conjugate, op.camp_index, op.camp_conjugate, op.T, op.H, op.W,
+                            **okw)
+    y64 = Obs(*[f.to(torch.complex128) if torch.is_complex(f) else f.double() for f in y.to_list()])
     for tag, xin in (("x", x), ("near", x_near)):
         o_ref = op(xin)
         o_orc = orc(xin)
+        out.update(obs_arrays(tag + "_obs64_", orc64(xin.double())))
+        g64, l64 = orc64.gradient(xin.double(), y64, return_loss=True)
+        out.update({tag + "_loss64": orc64.loss(xin.double(), y64)})
+        out.update({tag + "_grad64_sub": g64.flatten()[::97]} if full else {tag + "_grad64": g64})
         for n, a, b in zip(Obs._fields, o_ref.to_list(), o_orc):
             close(a, b, what="%s obs.%s" % (name, n))
         loss = op.loss(xin, y)

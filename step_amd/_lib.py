@@ -1,0 +1,105 @@
+"""ctypes binding of libstep_amd.so (C ABI: include/step_amd.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent the
+import of any operator raises, and every non-zero return code raises RuntimeError
+with the library's own message."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstep_amd.so")
+
+c_f = C.c_float
+c_i = C.c_int
+c_i64 = C.c_int64
+c_p = C.c_void_p
+
+
+class bh_tables_t(C.Structure):
+    _fields_ = [("n_vis", C.c_int32), ("n_tri", C.c_int32), ("n_quad", C.c_int32), ("T", C.c_int32),
+                ("cp_index", c_p), ("cp_conj", c_p), ("camp_index", c_p),
+                ("cp_ptr", c_p), ("cp_ent", c_p), ("ca_ptr", c_p), ("ca_ent", c_p)]
+
+
+class bh_meas_t(C.Structure):
+    _fields_ = [("vis_c64", c_p), ("sigma_vis", c_p), ("amp", c_p), ("sigma_amp", c_p),
+                ("cphase", c_p), ("sigma_cphase", c_p), ("logcamp", c_p), ("sigma_logcamp", c_p),
+                ("flux", c_p), ("batch", C.c_int32)]
+
+
+class bh_weights_t(C.Structure):
+    _fields_ = [("w_vis", c_f), ("w_amp", c_f), ("w_cp", c_f), ("w_camp", c_f), ("w_flux", c_f),
+                ("normalize", C.c_int32)]
+
+
+class mcmc_params_t(C.Structure):
+    _fields_ = [("inv_tau2", c_f), ("inv_sigma2", c_f), ("lr", c_f), ("sqrt_lr", c_f),
+                ("sqrt_2lr", c_f), ("momentum", c_f), ("noise_scale", c_f), ("algo", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/step_amd.h declares
+SIGNATURES = {
+    "step_last_error": (C.c_char_p, []),
+    "step_abi_version": (c_i, []),
+    "bh_build_closure_tables": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_i64,
+                                      c_p, c_p, c_p, c_p]),
+    "bh_build_incidence": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "mri_build_mask": (c_i, [c_i, c_i, c_i, c_i, c_i, c_p]),
+    "bh_dense_rows_padded": (c_i, [c_i]),
+    "bh_dense_packed_floats": (C.c_size_t, [c_i, c_i, c_i]),
+    "bh_dense_fwd_workspace_floats": (C.c_size_t, [c_i, c_i, c_i, c_i]),
+    "bh_dense_pack": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "bh_dft_fwd_dense": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "bh_dft_adj_dense": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p]),
+    "bh_dft_fwd_sep": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_f, c_f, c_p, c_p, c_p]),
+    "bh_dft_adj_sep": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p]),
+    "bh_closure_loss": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
+                              C.POINTER(bh_weights_t), c_p, c_p, c_p, c_p, c_p]),
+    "bh_closure_chisq": (c_i, [c_p, c_p, c_i, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
+                               c_p, c_p]),
+    "bh_closure_observe": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), c_p, c_p, c_p, c_p, c_p,
+                                 c_p, c_p]),
+    "mri_forward": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mri_adjoint": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mri_loss_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p,
+                            c_p]),
+    "mcmc_update": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "step_amd: %s is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C step_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().step_last_error()
+        raise RuntimeError("step_amd %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def stream_of(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream

@@ -1,0 +1,385 @@
+// Closure quantities over baseline triangles / quadrangles, their chi^2 terms, the
+// normalised weighted loss and its gradient w.r.t. the visibilities -- one workgroup per
+// chain, everything staged in LDS (a chain's visibilities are 14 KB at 64 x 28 baselines).
+//
+// Replaces, from forward_operator/blackhole.py: correct_vis_direction :332-334,
+// forward_bisepectra_from_vis :341-353, forward_cp_from_vis :355-363,
+// forward_logcamp_bispectra_from_vis :365-380, forward_logcamp_from_vis :382-391,
+// forward_amp_from_vis :336-339, chi2_* :448-491, normalize_chisq :665-669, the weighted
+// sum of loss :736-771, and the autograd backward of all of it.
+// The backward scatter over triangles/quadrangles is a gather through the transposed
+// incidence tables (bh_build_incidence), so results are bitwise reproducible.
+#include "common.h"
+
+#define CL_THREADS 256
+
+struct ClosureArgs {
+    bh_tables_t tab;
+    bh_meas_t y;
+    bh_weights_t w;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cdir(float2 v, int conj) {   // blackhole.py:332-334
+    return conj ? make_float2(v.x, -v.y) : v;
+}
+__device__ __forceinline__ float cabs(float2 v) { return hypotf(v.x, v.y); }
+
+// 1 - cos(d) as 2 sin^2(d/2): the reference's fp32 (1 - cos) cancels catastrophically once the
+// chain fits the data (d ~ 1e-3 leaves ~3 significant bits); this form stays accurate to fp32
+// rounding and is what the fp64 evaluation of the reference formula converges to.
+__device__ __forceinline__ float one_minus_cos(float d) {
+    const float s = sinf(0.5f * d);
+    return 2.0f * s * s;
+}
+
+// e(chi) and e'(chi) of normalize_chisq (no gradient through the comparison)
+__device__ __forceinline__ void fold(float chi, int normalize, float& e, float& de) {
+    if (normalize && chi < 1.0f) { e = 1.0f / chi; de = -1.0f / (chi * chi); }
+    else { e = chi; de = 1.0f; }
+}
+
+// LDS: sv float2[n_vis] | dcp float[n_tri] | dca float[n_quad] | red float[8]
+__global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
+    const float2* __restrict__ vis, const float* __restrict__ flux, ClosureArgs a,
+    float* __restrict__ loss, float* __restrict__ chi2, float2* __restrict__ gvis,
+    float* __restrict__ gflux) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int M = a.tab.n_vis, Kcp = a.tab.n_tri, Kca = a.tab.n_quad, T = a.tab.T;
+    float2* sv = (float2*)lds;
+    float* dcp = lds + 2 * (size_t)M;
+    float* dca = dcp + Kcp;
+    float* red = dca + Kca;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
+
+    for (int m = tid; m < M; m += CL_THREADS) sv[m] = vis[(size_t)b * M + m];
+    __syncthreads();
+
+    // --- closure phase: chi = 2 mean((1 - cos(y - phi)) / s^2), blackhole.py:472-474
+    float s_cp = 0.f;
+    if (a.w.w_cp > 0.f) {
+        const float* yv = a.y.cphase + yb * Kcp;
+        const float* ys = a.y.sigma_cphase + yb * Kcp;
+        for (int k = tid; k < Kcp; k += CL_THREADS) {
+            const float2 i1 = cdir(sv[a.tab.cp_index[3 * k + 0]], a.tab.cp_conj[3 * k + 0]);
+            const float2 i2 = cdir(sv[a.tab.cp_index[3 * k + 1]], a.tab.cp_conj[3 * k + 1]);
+            const float2 i3 = cdir(sv[a.tab.cp_index[3 * k + 2]], a.tab.cp_conj[3 * k + 2]);
+            const float2 p = cmul(cmul(i1, i2), i3);
+            const float phi = atan2f(p.y, p.x);
+            const float d = yv[k] - phi;
+            const float is2 = 1.0f / (ys[k] * ys[k]);
+            s_cp += one_minus_cos(d) * is2;
+            dcp[k] = -sinf(d) * is2;                       // d/dphi of (1 - cos(y - phi))/s^2
+        }
+    }
+    // --- log closure amplitude: chi = mean(((l - y)/s)^2), blackhole.py:482-483
+    float s_ca = 0.f;
+    if (a.w.w_camp > 0.f) {
+        const float* yv = a.y.logcamp + yb * Kca;
+        const float* ys = a.y.sigma_logcamp + yb * Kca;
+        for (int k = tid; k < Kca; k += CL_THREADS) {
+            const float a1 = cabs(sv[a.tab.camp_index[4 * k + 0]]);
+            const float a2 = cabs(sv[a.tab.camp_index[4 * k + 1]]);
+            const float a3 = cabs(sv[a.tab.camp_index[4 * k + 2]]);
+            const float a4 = cabs(sv[a.tab.camp_index[4 * k + 3]]);
+            const float l = logf(a1) + logf(a2) - logf(a3) - logf(a4);
+            const float r = (l - yv[k]) / ys[k];
+            s_ca += r * r;
+            dca[k] = 2.0f * r / ys[k];                     // d/dl of ((l - y)/s)^2
+        }
+    }
+    // --- visibility / amplitude terms (zero weight in the shipped config), :453-464
+    float s_vis = 0.f, s_amp = 0.f;
+    if (a.w.w_vis > 0.f) {
+        const float2* yv = (const float2*)a.y.vis_c64 + yb * M;
+        const float* ys = a.y.sigma_vis + yb * M;
+        for (int m = tid; m < M; m += CL_THREADS) {
+            const float r = cabs(make_float2(sv[m].x - yv[m].x, sv[m].y - yv[m].y)) / ys[m];
+            s_vis += r * r;
+        }
+    }
+    if (a.w.w_amp > 0.f) {
+        const float* yv = a.y.amp + yb * M;
+        const float* ys = a.y.sigma_amp + yb * M;
+        for (int m = tid; m < M; m += CL_THREADS) {
+            const float r = (cabs(sv[m]) - yv[m]) / ys[m];
+            s_amp += r * r;
+        }
+    }
+    // --- flux: mean(((f - y)/2)^2), :490-491
+    float s_fl = 0.f;
+    if (a.w.w_flux > 0.f) {
+        const float* yv = a.y.flux + yb * T;
+        for (int t = tid; t < T; t += CL_THREADS) {
+            const float r = (flux[(size_t)b * T + t] - yv[t]) * 0.5f;
+            s_fl += r * r;
+        }
+    }
+    const float chi_cp = a.w.w_cp > 0.f ? 2.0f * block_sum(s_cp, red) / Kcp : 0.f;
+    const float chi_ca = a.w.w_camp > 0.f ? block_sum(s_ca, red) / Kca : 0.f;
+    const float chi_vis = a.w.w_vis > 0.f ? block_sum(s_vis, red) / M * 0.5f : 0.f;
+    const float chi_amp = a.w.w_amp > 0.f ? block_sum(s_amp, red) / M : 0.f;
+    const float chi_fl = a.w.w_flux > 0.f ? block_sum(s_fl, red) / T : 0.f;
+
+    float e_cp = 0.f, d_cp = 0.f, e_ca = 0.f, d_ca = 0.f, e_vis = 0.f, d_vis = 0.f, e_amp = 0.f,
+          d_amp = 0.f;
+    if (a.w.w_cp > 0.f) fold(chi_cp, a.w.normalize, e_cp, d_cp);
+    if (a.w.w_camp > 0.f) fold(chi_ca, a.w.normalize, e_ca, d_ca);
+    if (a.w.w_vis > 0.f) fold(chi_vis, a.w.normalize, e_vis, d_vis);
+    if (a.w.w_amp > 0.f) fold(chi_amp, a.w.normalize, e_amp, d_amp);
+    if (tid == 0) {
+        // same accumulation order as loss(): vis, amp, cp, camp, flux (blackhole.py:742-769)
+        float L = 0.f;
+        if (a.w.w_vis > 0.f) L += a.w.w_vis * e_vis;
+        if (a.w.w_amp > 0.f) L += a.w.w_amp * e_amp;
+        if (a.w.w_cp > 0.f) L += a.w.w_cp * e_cp;
+        if (a.w.w_camp > 0.f) L += a.w.w_camp * e_ca;
+        if (a.w.w_flux > 0.f) L += a.w.w_flux * chi_fl;
+        loss[b] = L;
+        if (chi2) {
+            chi2[b * 5 + 0] = chi_vis; chi2[b * 5 + 1] = chi_amp; chi2[b * 5 + 2] = chi_cp;
+            chi2[b * 5 + 3] = chi_ca;  chi2[b * 5 + 4] = chi_fl;
+        }
+    }
+    if (!gvis) return;
+
+    // --- backward: dL/dchi factors, then gather per baseline through the incidence tables
+    const float f_cp = a.w.w_cp * d_cp * 2.0f / Kcp;
+    const float f_ca = a.w.w_camp * d_ca / Kca;
+    const float f_vis = a.w.w_vis * d_vis / M;          // d/dv of |v-y|^2/(2 s^2 M) = (v-y)/(s^2 M)
+    const float f_amp = a.w.w_amp * d_amp * 2.0f / M;
+    __syncthreads();                                     // dcp / dca complete
+    for (int m = tid; m < M; m += CL_THREADS) {
+        const float2 v = sv[m];
+        const float n2 = v.x * v.x + v.y * v.y;
+        float gp = 0.f, gl = 0.f;                        // coefficients of i v/|v|^2 and v/|v|^2
+        if (a.w.w_cp > 0.f) {
+            for (int e = a.tab.cp_ptr[m]; e < a.tab.cp_ptr[m + 1]; ++e) {
+                const int ent = a.tab.cp_ent[e];
+                const float d = dcp[ent >> 3];
+                gp += (ent & 1) ? -d : d;                // conj leg: arg(conj v) = -arg v
+            }
+            gp *= f_cp;
+        }
+        if (a.w.w_camp > 0.f) {
+            for (int e = a.tab.ca_ptr[m]; e < a.tab.ca_ptr[m + 1]; ++e) {
+                const int ent = a.tab.ca_ent[e];
+                const float d = dca[ent >> 3];
+                gl += (((ent >> 1) & 3) < 2) ? d : -d;   // legs 0,1 numerator, 2,3 denominator
+            }
+            gl *= f_ca;
+        }
+        float gx = 0.f, gy = 0.f;
+        if (a.w.w_cp > 0.f || a.w.w_camp > 0.f) {
+            gx = (gl * v.x - gp * v.y) / n2;
+            gy = (gl * v.y + gp * v.x) / n2;
+        }
+        if (a.w.w_vis > 0.f) {
+            const float2 yv = ((const float2*)a.y.vis_c64 + yb * M)[m];
+            const float s = (a.y.sigma_vis + yb * M)[m];
+            gx += f_vis * (v.x - yv.x) / (s * s);
+            gy += f_vis * (v.y - yv.y) / (s * s);
+        }
+        if (a.w.w_amp > 0.f) {
+            const float s = (a.y.sigma_amp + yb * M)[m];
+            const float am = sqrtf(n2);
+            const float c = f_amp * (am - (a.y.amp + yb * M)[m]) / (s * s) / am;
+            gx += c * v.x;
+            gy += c * v.y;
+        }
+        gvis[(size_t)b * M + m] = make_float2(gx, gy);
+    }
+    for (int t = tid; t < T; t += CL_THREADS) {
+        float g = 0.f;
+        if (a.w.w_flux > 0.f)
+            g = a.w.w_flux * (flux[(size_t)b * T + t] - (a.y.flux + yb * T)[t]) * 0.5f / T;
+        gflux[(size_t)b * T + t] = g;
+    }
+}
+
+static int check_tables(const char* who, const bh_tables_t* tab) {
+    STEP_REQUIRE(tab, "%s: null tables", who);
+    STEP_REQUIRE(tab->n_vis > 0 && tab->n_tri >= 0 && tab->n_quad >= 0 && tab->T > 0,
+                 "%s: bad table sizes", who);
+    STEP_REQUIRE(tab->n_tri == 0 || (tab->cp_index && tab->cp_conj), "%s: null cp tables", who);
+    STEP_REQUIRE(tab->n_quad == 0 || tab->camp_index, "%s: null camp tables", who);
+    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 16) * sizeof(float);
+    STEP_REQUIRE(lds <= 150 * 1024, "%s: tables need %zu B of LDS (max 150 KiB)", who, lds);
+    return STEP_OK;
+}
+
+extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
+                               const bh_tables_t* tab, const bh_meas_t* y, const bh_weights_t* w,
+                               float* loss, float* chi2, float* gvis_c64, float* gflux,
+                               void* stream) {
+    STEP_REQUIRE(vis_c64 && flux && y && w && loss && B > 0, "bh_closure_loss: null pointer / B");
+    if (int rc = check_tables("bh_closure_loss", tab)) return rc;
+    STEP_REQUIRE((gvis_c64 == nullptr) == (gflux == nullptr), "bh_closure_loss: gvis and gflux go together");
+    STEP_REQUIRE(y->batch == 1 || y->batch == B, "bh_closure_loss: measurement batch %d vs B=%d", y->batch, B);
+    STEP_REQUIRE(!(w->w_cp > 0) || (tab->n_tri > 0 && y->cphase && y->sigma_cphase), "bh_closure_loss: cphase data missing");
+    STEP_REQUIRE(!(w->w_camp > 0) || (tab->n_quad > 0 && y->logcamp && y->sigma_logcamp), "bh_closure_loss: logcamp data missing");
+    STEP_REQUIRE(!(w->w_vis > 0) || (y->vis_c64 && y->sigma_vis), "bh_closure_loss: vis data missing");
+    STEP_REQUIRE(!(w->w_amp > 0) || (y->amp && y->sigma_amp), "bh_closure_loss: amp data missing");
+    STEP_REQUIRE(!(w->w_flux > 0) || y->flux, "bh_closure_loss: flux data missing");
+    STEP_REQUIRE(!gvis_c64 || ((!(w->w_cp > 0) || (tab->cp_ptr && tab->cp_ent)) &&
+                               (!(w->w_camp > 0) || (tab->ca_ptr && tab->ca_ent))),
+                 "bh_closure_loss: incidence tables missing");
+    ClosureArgs a{*tab, *y, *w};
+    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 16) * sizeof(float);
+    step_allow_lds((const void*)k_closure_loss, lds);
+    hipLaunchKernelGGL(k_closure_loss, dim3(B), dim3(CL_THREADS), lds, (hipStream_t)stream,
+                       (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
+    STEP_CHECK_LAUNCH("bh_closure_loss");
+    return STEP_OK;
+}
+
+// ------------------------------------------------------------------------------- evaluator chi^2
+__global__ __launch_bounds__(CL_THREADS) void k_closure_chisq(
+    const float2* __restrict__ vis, const float* __restrict__ vis_scale, int F, ClosureArgs a,
+    float* __restrict__ chi2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int M = a.tab.n_vis, Kcp = a.tab.n_tri, Kca = a.tab.n_quad, T = a.tab.T;
+    float2* sv = (float2*)lds;
+    float* red = lds + 2 * (size_t)M;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
+    for (int m = tid; m < M; m += CL_THREADS) {
+        float2 v = vis[(size_t)b * M + m];
+        if (vis_scale) {
+            const float s = vis_scale[(size_t)b * T + m / F];
+            v.x *= s; v.y *= s;
+        }
+        sv[m] = v;
+    }
+    __syncthreads();
+    float s_vis = 0.f, s_amp = 0.f, s_cp = 0.f, s_ca = 0.f;
+    if (a.y.vis_c64 && a.y.sigma_vis) {
+        const float2* yv = (const float2*)a.y.vis_c64 + yb * M;
+        const float* ys = a.y.sigma_vis + yb * M;
+        for (int m = tid; m < M; m += CL_THREADS) {
+            const float r = cabs(make_float2(sv[m].x - yv[m].x, sv[m].y - yv[m].y)) / ys[m];
+            s_vis += r * r;
+        }
+    }
+    if (a.y.amp && a.y.sigma_amp) {
+        const float* yv = a.y.amp + yb * M;
+        const float* ys = a.y.sigma_amp + yb * M;
+        for (int m = tid; m < M; m += CL_THREADS) {
+            const float r = (cabs(sv[m]) - yv[m]) / ys[m];
+            s_amp += r * r;
+        }
+    }
+    if (a.y.cphase && a.y.sigma_cphase) {
+        const float* yv = a.y.cphase + yb * Kcp;
+        const float* ys = a.y.sigma_cphase + yb * Kcp;
+        for (int k = tid; k < Kcp; k += CL_THREADS) {
+            const float2 i1 = cdir(sv[a.tab.cp_index[3 * k + 0]], a.tab.cp_conj[3 * k + 0]);
+            const float2 i2 = cdir(sv[a.tab.cp_index[3 * k + 1]], a.tab.cp_conj[3 * k + 1]);
+            const float2 i3 = cdir(sv[a.tab.cp_index[3 * k + 2]], a.tab.cp_conj[3 * k + 2]);
+            const float2 p = cmul(cmul(i1, i2), i3);
+            s_cp += one_minus_cos(yv[k] - atan2f(p.y, p.x)) / (ys[k] * ys[k]);
+        }
+    }
+    if (a.y.logcamp && a.y.sigma_logcamp) {
+        const float* yv = a.y.logcamp + yb * Kca;
+        const float* ys = a.y.sigma_logcamp + yb * Kca;
+        for (int k = tid; k < Kca; k += CL_THREADS) {
+            const float l = logf(cabs(sv[a.tab.camp_index[4 * k + 0]])) +
+                            logf(cabs(sv[a.tab.camp_index[4 * k + 1]])) -
+                            logf(cabs(sv[a.tab.camp_index[4 * k + 2]])) -
+                            logf(cabs(sv[a.tab.camp_index[4 * k + 3]]));
+            const float r = (l - yv[k]) / ys[k];
+            s_ca += r * r;
+        }
+    }
+    const float c_vis = block_sum(s_vis, red) / M * 0.5f;
+    const float c_amp = block_sum(s_amp, red) / M;
+    const float c_cp = Kcp ? 2.0f * block_sum(s_cp, red) / Kcp : 0.f;
+    const float c_ca = Kca ? block_sum(s_ca, red) / Kca : 0.f;
+    if (tid == 0) {
+        chi2[b * 4 + 0] = c_vis; chi2[b * 4 + 1] = c_amp; chi2[b * 4 + 2] = c_cp; chi2[b * 4 + 3] = c_ca;
+    }
+}
+
+extern "C" int bh_closure_chisq(const float* vis_c64, const float* vis_scale, int B, int F,
+                                const bh_tables_t* tab, const bh_meas_t* y, float* chi2,
+                                void* stream) {
+    STEP_REQUIRE(vis_c64 && y && chi2 && B > 0 && F > 0, "bh_closure_chisq: null pointer / sizes");
+    if (int rc = check_tables("bh_closure_chisq", tab)) return rc;
+    STEP_REQUIRE(tab->n_vis == tab->T * F, "bh_closure_chisq: n_vis != T*F");
+    STEP_REQUIRE(y->batch == 1 || y->batch == B, "bh_closure_chisq: measurement batch %d vs B=%d", y->batch, B);
+    ClosureArgs a{*tab, *y, bh_weights_t{0, 0, 0, 0, 0, 0}};
+    const size_t lds = (2 * (size_t)tab->n_vis + 16) * sizeof(float);
+    step_allow_lds((const void*)k_closure_chisq, lds);
+    hipLaunchKernelGGL(k_closure_chisq, dim3(B), dim3(CL_THREADS), lds, (hipStream_t)stream,
+                       (const float2*)vis_c64, vis_scale, F, a, chi2);
+    STEP_CHECK_LAUNCH("bh_closure_chisq");
+    return STEP_OK;
+}
+
+// ------------------------------------------------------------------------------- observation
+__global__ __launch_bounds__(CL_THREADS) void k_closure_observe(
+    const float2* __restrict__ vis, const float* __restrict__ sigma, bh_tables_t tab,
+    float* __restrict__ amp, float* __restrict__ sigma_amp, float* __restrict__ cphase,
+    float* __restrict__ sigma_cp, float* __restrict__ logcamp, float* __restrict__ sigma_ca) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int M = tab.n_vis, Kcp = tab.n_tri, Kca = tab.n_quad;
+    float2* sv = (float2*)lds;
+    float* ss = lds + 2 * (size_t)M;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int m = tid; m < M; m += CL_THREADS) {
+        const float2 v = vis[(size_t)b * M + m];
+        sv[m] = v;
+        ss[m] = sigma[m];
+        amp[(size_t)b * M + m] = cabs(v);
+        sigma_amp[(size_t)b * M + m] = sigma[m] + 0.f * cabs(v);   // blackhole.py:338 (NaN/inf propagate)
+    }
+    __syncthreads();
+    for (int k = tid; k < Kcp; k += CL_THREADS) {
+        float s2 = 0.f;
+        float2 p = make_float2(1.f, 0.f);
+        float2 leg[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int m = tab.cp_index[3 * k + j];
+            leg[j] = cdir(sv[m], tab.cp_conj[3 * k + j]);
+            const float am = cabs(leg[j]);
+            s2 += ss[m] * ss[m] / (am * am);
+        }
+        p = cmul(cmul(leg[0], leg[1]), leg[2]);
+        cphase[(size_t)b * Kcp + k] = atan2f(p.y, p.x);
+        sigma_cp[(size_t)b * Kcp + k] = sqrtf(s2);
+    }
+    for (int k = tid; k < Kca; k += CL_THREADS) {
+        float s2 = 0.f, l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = tab.camp_index[4 * k + j];
+            const float am = cabs(sv[m]);
+            s2 += ss[m] * ss[m] / (am * am);
+            l += (j < 2) ? logf(am) : -logf(am);
+        }
+        logcamp[(size_t)b * Kca + k] = l;
+        sigma_ca[(size_t)b * Kca + k] = sqrtf(s2);
+    }
+}
+
+extern "C" int bh_closure_observe(const float* vis_c64, const float* sigma, int B,
+                                  const bh_tables_t* tab, float* amp, float* sigma_amp,
+                                  float* cphase, float* sigma_cphase, float* logcamp,
+                                  float* sigma_logcamp, void* stream) {
+    STEP_REQUIRE(vis_c64 && sigma && amp && sigma_amp && B > 0, "bh_closure_observe: null pointer / B");
+    if (int rc = check_tables("bh_closure_observe", tab)) return rc;
+    STEP_REQUIRE(tab->n_tri == 0 || (cphase && sigma_cphase), "bh_closure_observe: null cphase outputs");
+    STEP_REQUIRE(tab->n_quad == 0 || (logcamp && sigma_logcamp), "bh_closure_observe: null logcamp outputs");
+    const size_t lds = (3 * (size_t)tab->n_vis + 16) * sizeof(float);
+    step_allow_lds((const void*)k_closure_observe, lds);
+    hipLaunchKernelGGL(k_closure_observe, dim3(B), dim3(CL_THREADS), lds, (hipStream_t)stream,
+                       (const float2*)vis_c64, sigma, *tab, amp, sigma_amp, cphase, sigma_cphase,
+                       logcamp, sigma_logcamp);
+    STEP_CHECK_LAUNCH("bh_closure_observe");
+    return STEP_OK;
+}

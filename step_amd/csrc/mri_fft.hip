@@ -1,0 +1,371 @@
+// Dynamic-MRI operator fused per frame: complex pack -> fftshift -> 2-D FFT -> k-space row
+// mask (forward_operator/dynamic_mri.py:42-48), and for the Langevin step the residual,
+// the per-chain loss of base.py:40-41 and the adjoint (SURVEY Appendix B "MRI") in the same
+// launch, so a step moves 24*R*R bytes per frame: read x, read y, write grad.
+//
+// One workgroup (512 threads) per frame, 192 = 16 x 12 in-register FFT passes over LDS:
+//   1. per 32-column strip: load x, FFT along y (all 192 rows), keep only the masked k_y rows
+//      (52 of 192 at acc 6 / 24 ACS lines) in an LDS row buffer  -> 80 KB instead of 295 KB
+//   2. FFT along x on the kept rows                               = M * FFT2(x)
+//   3. residual against y, loss, scale by 2                      (kept rows only carry gradient)
+//   4. inverse FFT along x on the kept rows
+//   5. per strip: scatter the kept rows into a zero strip, inverse FFT along y, store grad
+// fftshift before the FFT is a roll by R/2 in both axes, i.e. a sign (-1)^(ky+kx) on the
+// spectrum; the ifftshift of the adjoint is the same sign on its input.  No data is moved.
+// Masks with more kept rows than the LDS row buffer holds are processed in groups (the
+// gradient then accumulates over groups).
+#include "common.h"
+#include "fft_small.h"
+
+#define MRI_R 192
+#define MRI_THREADS 512
+#define MRI_SW 32                 // strip width (columns)
+#define MRI_RS 204                // row-buffer stride in complex elements (conflict-free pass A)
+#define MRI_NKC_MAX 64
+
+struct MriLds {
+    cf32* tw;      // [192]
+    cf32* S;       // [192][32]
+    cf32* Rk;      // [nkc][204]
+    int* rowpos;   // [192]
+    float* red;    // [16]
+};
+
+__device__ __forceinline__ MriLds carve(float* lds, int nkc) {
+    MriLds L;
+    L.tw = (cf32*)lds;
+    L.S = L.tw + MRI_R;
+    L.Rk = L.S + MRI_R * MRI_SW;
+    L.rowpos = (int*)(L.Rk + (size_t)nkc * MRI_RS);
+    L.red = (float*)(L.rowpos + MRI_R);
+    return L;
+}
+static size_t mri_lds_bytes(int nkc) {
+    return (size_t)(MRI_R + MRI_R * MRI_SW + (size_t)nkc * MRI_RS) * sizeof(cf32) +
+           MRI_R * sizeof(int) + 16 * sizeof(float);
+}
+
+__device__ __forceinline__ float sgn(int k) { return (k & 1) ? -1.f : 1.f; }
+
+// FFT along y of the strip S[192][32] (all 32 columns), in place, natural order.
+template <int SIGN>
+__device__ __forceinline__ void strip_fft_y(const MriLds& L) {
+    const int tid = threadIdx.x, col = tid & 31;
+    if (tid < 12 * 32) {
+        const int bb = tid >> 5;
+        cf32 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = L.S[(12 * a + bb) * MRI_SW + col];
+        fft192_pass_a<SIGN>(v, bb, L.tw);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * MRI_SW + col] = v[c];
+    }
+    __syncthreads();
+    {
+        const int c = tid >> 5;                       // 16 x 32 tasks = 512 threads
+        cf32 v[12];
+#pragma unroll
+        for (int b = 0; b < 12; ++b) v[b] = L.S[(12 * c + b) * MRI_SW + col];
+        fft192_pass_b<SIGN>(v);
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 12; ++d) L.S[(c + 16 * d) * MRI_SW + col] = v[d];
+    }
+    __syncthreads();
+}
+
+// FFT along x of the nk kept rows Rk[nk][204], in place, natural order.
+template <int SIGN>
+__device__ __forceinline__ void rows_fft_x(const MriLds& L, int nk) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < nk * 12; e += MRI_THREADS) {
+        const int j = e / 12, bb = e - 12 * j;
+        cf32* row = L.Rk + (size_t)j * MRI_RS;
+        cf32 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = row[12 * a + bb];
+        fft192_pass_a<SIGN>(v, bb, L.tw);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[12 * c + bb] = v[c];
+    }
+    __syncthreads();
+    // nk * 16 <= 1024 tasks: at most two per thread, all reads before any write
+    cf32 v0[12], v1[12];
+    const int e0 = tid, e1 = tid + MRI_THREADS;
+    const bool has0 = e0 < nk * 16, has1 = e1 < nk * 16;
+    if (has0) {
+        const cf32* row = L.Rk + (size_t)(e0 >> 4) * MRI_RS + 12 * (e0 & 15);
+#pragma unroll
+        for (int b = 0; b < 12; ++b) v0[b] = row[b];
+        fft192_pass_b<SIGN>(v0);
+    }
+    if (has1) {
+        const cf32* row = L.Rk + (size_t)(e1 >> 4) * MRI_RS + 12 * (e1 & 15);
+#pragma unroll
+        for (int b = 0; b < 12; ++b) v1[b] = row[b];
+        fft192_pass_b<SIGN>(v1);
+    }
+    __syncthreads();
+    if (has0) {
+        cf32* row = L.Rk + (size_t)(e0 >> 4) * MRI_RS + (e0 & 15);
+#pragma unroll
+        for (int d = 0; d < 12; ++d) row[16 * d] = v0[d];
+    }
+    if (has1) {
+        cf32* row = L.Rk + (size_t)(e1 >> 4) * MRI_RS + (e1 & 15);
+#pragma unroll
+        for (int d = 0; d < 12; ++d) row[16 * d] = v1[d];
+    }
+    __syncthreads();
+}
+
+// Steps 1-2 for kept rows [g0, g0+nk): leaves Rk[j][kx] = (-1)^ky * FFT2(z)[ky][kx], ky = rowlist[g0+j]
+__device__ __forceinline__ void forward_rows(const MriLds& L, const float* __restrict__ xr,
+                                             const float* __restrict__ xi,
+                                             const int* __restrict__ rowlist, int g0, int nk) {
+    const int tid = threadIdx.x;
+    for (int strip = 0; strip < MRI_R / MRI_SW; ++strip) {
+        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) {
+            const int row = e >> 5, col = e & 31;
+            const size_t g = (size_t)row * MRI_R + strip * MRI_SW + col;
+            L.S[e] = c_make(xr[g], xi[g]);
+        }
+        __syncthreads();
+        strip_fft_y<-1>(L);
+        for (int e = tid; e < nk * MRI_SW; e += MRI_THREADS) {
+            const int j = e >> 5, col = e & 31;
+            const int ky = rowlist[g0 + j];
+            const cf32 v = L.S[ky * MRI_SW + col];
+            const float s = sgn(ky);
+            L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col] = c_make(s * v.x, s * v.y);
+        }
+        __syncthreads();
+    }
+    rows_fft_x<-1>(L, nk);
+}
+
+__device__ __forceinline__ void load_tables(const MriLds& L, const int* __restrict__ rowlist,
+                                            int nk_total) {
+    for (int e = threadIdx.x; e < MRI_R; e += MRI_THREADS) {
+        float sn, cn;
+        sincospif((float)e * (1.0f / 96.0f), &sn, &cn);      // (cos, sin)(2 pi e / 192)
+        L.tw[e] = c_make(cn, sn);
+        L.rowpos[e] = -1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nk_total; e += MRI_THREADS) L.rowpos[rowlist[e]] = e;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------- forward only
+__global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
+    const float* __restrict__ x, const int* __restrict__ rows, const int* __restrict__ nrows,
+    int mask_frames, int T, int nkc, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MriLds L = carve(lds, nkc);
+    const int frame = blockIdx.x, t = frame % T, tid = threadIdx.x;
+    const int mf = mask_frames == 1 ? 0 : t;
+    const int* rowlist = rows + (size_t)mf * MRI_R;
+    const int nk_total = nrows[mf];
+    const float* xr = x + (size_t)frame * 2 * MRI_R * MRI_R;
+    const float* xi = xr + MRI_R * MRI_R;
+    float* outr = out + (size_t)frame * 2 * MRI_R * MRI_R;
+    float* outi = outr + MRI_R * MRI_R;
+    load_tables(L, rowlist, nk_total);
+    for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS)
+        if (L.rowpos[e / MRI_R] < 0) { outr[e] = 0.f; outi[e] = 0.f; }
+    for (int g0 = 0; g0 < nk_total; g0 += nkc) {
+        const int nk = min(nkc, nk_total - g0);
+        forward_rows(L, xr, xi, rowlist, g0, nk);
+        for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
+            const int j = e / MRI_R, kx = e - j * MRI_R;
+            const int ky = rowlist[g0 + j];
+            const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
+            const float s = sgn(kx);
+            outr[(size_t)ky * MRI_R + kx] = s * v.x;
+            outi[(size_t)ky * MRI_R + kx] = s * v.y;
+        }
+        __syncthreads();
+    }
+}
+
+// Steps 4-5 for kept rows [g0, g0+nk): Rk holds the (sign-folded) k-space rows; writes (g0 == 0)
+// or accumulates (later groups) the image-space result into the frame `dst` ([2][R][R]).
+__device__ __forceinline__ void adjoint_rows(const MriLds& L, const int* __restrict__ rowlist,
+                                             int g0, int nk, float* __restrict__ dst) {
+    const int tid = threadIdx.x;
+    rows_fft_x<1>(L, nk);
+    float* dr = dst;
+    float* di = dst + MRI_R * MRI_R;
+    for (int strip = 0; strip < MRI_R / MRI_SW; ++strip) {
+        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) L.S[e] = c_make(0.f, 0.f);
+        __syncthreads();
+        for (int e = tid; e < nk * MRI_SW; e += MRI_THREADS) {
+            const int j = e >> 5, col = e & 31;
+            L.S[rowlist[g0 + j] * MRI_SW + col] = L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col];
+        }
+        __syncthreads();
+        strip_fft_y<1>(L);
+        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) {
+            const int row = e >> 5, col = e & 31;
+            const size_t g = (size_t)row * MRI_R + strip * MRI_SW + col;
+            const cf32 v = L.S[e];
+            if (g0 == 0) { dr[g] = v.x; di[g] = v.y; }
+            else { dr[g] += v.x; di[g] += v.y; }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------- loss + gradient
+__global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
+    const float* __restrict__ x, const float* __restrict__ y, int y_batch,
+    const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T, int nkc,
+    const float* __restrict__ chain_scale, float* __restrict__ loss_part, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MriLds L = carve(lds, nkc);
+    const int frame = blockIdx.x, b = frame / T, t = frame % T, tid = threadIdx.x;
+    const int mf = mask_frames == 1 ? 0 : t;
+    const int* rowlist = rows + (size_t)mf * MRI_R;
+    const int nk_total = nrows[mf];
+    const size_t fsz = (size_t)2 * MRI_R * MRI_R;
+    const float* xr = x + (size_t)frame * fsz;
+    const float* xi = xr + MRI_R * MRI_R;
+    const float* yr = y + ((size_t)(y_batch > 1 ? b : 0) * T + t) * fsz;
+    const float* yi = yr + MRI_R * MRI_R;
+    const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
+    load_tables(L, rowlist, nk_total);
+
+    // rows outside the mask: A(x) = 0 there, the residual is -y (constant in x)
+    float acc = 0.f;
+    for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS)
+        if (L.rowpos[e / MRI_R] < 0) acc += yr[e] * yr[e] + yi[e] * yi[e];
+
+    if (nk_total == 0 && grad) {
+        float* gr = grad + (size_t)frame * fsz;
+        for (int e = tid; e < 2 * MRI_R * MRI_R; e += MRI_THREADS) gr[e] = 0.f;
+    }
+    for (int g0 = 0; g0 < nk_total; g0 += nkc) {
+        const int nk = min(nkc, nk_total - g0);
+        forward_rows(L, xr, xi, rowlist, g0, nk);
+        // residual, loss, adjoint input 2 * (-1)^(ky+kx) * r  (the row sign is already in Rk)
+        for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
+            const int j = e / MRI_R, kx = e - j * MRI_R;
+            const int ky = rowlist[g0 + j];
+            const float sx = sgn(kx), sy = sgn(ky);
+            const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
+            const float rr = sx * v.x - yr[(size_t)ky * MRI_R + kx];
+            const float ri = sx * v.y - yi[(size_t)ky * MRI_R + kx];
+            acc += rr * rr + ri * ri;
+            const float s = cs2 * sx * sy;
+            L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
+        }
+        __syncthreads();
+        if (grad) adjoint_rows(L, rowlist, g0, nk, grad + (size_t)frame * fsz);
+    }
+    const float tot = block_sum(acc, L.red);
+    if (tid == 0) loss_part[frame] = tot;
+}
+
+// ------------------------------------------------------------------------------- adjoint only
+// out = A^H g = ifftshift( R^2 * IFFT2( M * g ) ): the vector-Jacobian product of mri_forward.
+__global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
+    const float* __restrict__ g, const int* __restrict__ rows, const int* __restrict__ nrows,
+    int mask_frames, int T, int nkc, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MriLds L = carve(lds, nkc);
+    const int frame = blockIdx.x, t = frame % T, tid = threadIdx.x;
+    const int mf = mask_frames == 1 ? 0 : t;
+    const int* rowlist = rows + (size_t)mf * MRI_R;
+    const int nk_total = nrows[mf];
+    const size_t fsz = (size_t)2 * MRI_R * MRI_R;
+    const float* gr = g + (size_t)frame * fsz;
+    const float* gi = gr + MRI_R * MRI_R;
+    load_tables(L, rowlist, nk_total);
+    if (nk_total == 0)
+        for (int e = tid; e < 2 * MRI_R * MRI_R; e += MRI_THREADS) out[(size_t)frame * fsz + e] = 0.f;
+    for (int g0 = 0; g0 < nk_total; g0 += nkc) {
+        const int nk = min(nkc, nk_total - g0);
+        for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
+            const int j = e / MRI_R, kx = e - j * MRI_R;
+            const int ky = rowlist[g0 + j];
+            const float s = sgn(kx) * sgn(ky);
+            L.Rk[(size_t)j * MRI_RS + kx] =
+                c_make(s * gr[(size_t)ky * MRI_R + kx], s * gi[(size_t)ky * MRI_R + kx]);
+        }
+        __syncthreads();
+        adjoint_rows(L, rowlist, g0, nk, out + (size_t)frame * fsz);
+    }
+}
+
+__global__ void k_mri_loss_finish(const float* __restrict__ part, int B, int T,
+                                  float* __restrict__ loss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += part[(size_t)b * T + t];
+    loss[b] = s;
+}
+
+static int mri_check(const char* who, int B, int T, int R, const int32_t* rows,
+                     const int32_t* nrows, int mask_frames) {
+    STEP_REQUIRE(B > 0 && T > 0, "%s: bad sizes B=%d T=%d", who, B, T);
+    STEP_REQUIRE(R == MRI_R, "%s: only resolution %d is built (got %d)", who, MRI_R, R);
+    STEP_REQUIRE(rows && nrows, "%s: null mask row tables", who);
+    STEP_REQUIRE(mask_frames == 1 || mask_frames == T, "%s: mask_frames=%d must be 1 or T=%d", who, mask_frames, T);
+    return STEP_OK;
+}
+
+// nkc = rows of the LDS row buffer; max_rows = the largest kept-row count of any mask frame
+// (host knowledge: the row tables are built on the host).  Larger masks run in groups of 64.
+static int pick_nkc(int max_rows) {
+    int n = max_rows < 1 ? 1 : max_rows;
+    return n > MRI_NKC_MAX ? MRI_NKC_MAX : n;
+}
+
+extern "C" int mri_forward(const float* x, int B, int T, int R, const int32_t* rows,
+                           const int32_t* nrows, int mask_frames, int max_rows, float* out,
+                           void* stream) {
+    STEP_REQUIRE(x && out, "mri_forward: null pointer");
+    if (int rc = mri_check("mri_forward", B, T, R, rows, nrows, mask_frames)) return rc;
+    const int nkc = pick_nkc(max_rows);
+    const size_t lds = mri_lds_bytes(nkc);
+    step_allow_lds((const void*)k_mri_forward, lds);
+    hipLaunchKernelGGL(k_mri_forward, dim3(B * T), dim3(MRI_THREADS), lds, (hipStream_t)stream, x,
+                       rows, nrows, mask_frames, T, nkc, out);
+    STEP_CHECK_LAUNCH("mri_forward");
+    return STEP_OK;
+}
+
+extern "C" int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows,
+                           const int32_t* nrows, int mask_frames, int max_rows, float* out,
+                           void* stream) {
+    STEP_REQUIRE(g && out, "mri_adjoint: null pointer");
+    if (int rc = mri_check("mri_adjoint", B, T, R, rows, nrows, mask_frames)) return rc;
+    const int nkc = pick_nkc(max_rows);
+    const size_t lds = mri_lds_bytes(nkc);
+    step_allow_lds((const void*)k_mri_adjoint, lds);
+    hipLaunchKernelGGL(k_mri_adjoint, dim3(B * T), dim3(MRI_THREADS), lds, (hipStream_t)stream, g,
+                       rows, nrows, mask_frames, T, nkc, out);
+    STEP_CHECK_LAUNCH("mri_adjoint");
+    return STEP_OK;
+}
+
+extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
+                             const int32_t* rows, const int32_t* nrows, int mask_frames,
+                             int max_rows, const float* chain_scale, float* loss_part, float* loss,
+                             float* grad, void* stream) {
+    STEP_REQUIRE(x && y && loss_part && loss, "mri_loss_grad: null pointer");
+    STEP_REQUIRE(y_batch == 1 || y_batch == B, "mri_loss_grad: measurement batch %d vs B=%d", y_batch, B);
+    if (int rc = mri_check("mri_loss_grad", B, T, R, rows, nrows, mask_frames)) return rc;
+    const int nkc = pick_nkc(max_rows);
+    const size_t lds = mri_lds_bytes(nkc);
+    step_allow_lds((const void*)k_mri_loss_grad, lds);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_mri_loss_grad, dim3(B * T), dim3(MRI_THREADS), lds, s, x, y, y_batch, rows,
+                       nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
+    STEP_CHECK_LAUNCH("mri_loss_grad");
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3((B + 255) / 256), dim3(256), 0, s, loss_part, B, T, loss);
+    STEP_CHECK_LAUNCH("mri_loss_finish");
+    return STEP_OK;
+}

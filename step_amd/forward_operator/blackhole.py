@@ -1,0 +1,501 @@
+"""Black-hole interferometric imaging operator on MI355X kernels, behind the reference's
+interface (reference forward_operator/blackhole.py): registry name ``'blackhole'``, the same
+constructor kwargs, ``__call__`` / ``loss`` / ``gradient`` / ``evaluate_chisq`` and the
+``BlackHoleObservation`` measurement container.
+
+Two kernel paths compute the same contraction vis = A_vis x:
+  * ``sep``   -- A_vis is kept as its rank-1 factors (what ehtim's ftmatrix produces), never
+                 materialised; used when the operator is built from uv coordinates;
+  * ``dense`` -- an arbitrary complex A_vis tensor (``from_tensors``), packed once for MFMA.
+The set-up that the reference delegates to ehtim (array file -> uv, sigma, closure sets) is
+done by ``step_amd.eht_lite`` (PARITY UNPINNED, see there); pass ``obs_table=`` to supply it.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, eht_lite
+from .base import Operator, register_operator
+
+__all__ = ["BlackHoleObservation", "BlackHoleImagingTorch"]
+
+_NEG_INF = float("-inf")
+
+
+class BlackHoleObservation(object):
+    """Nine-field measurement (reference blackhole.py:23-132); ``to_list`` order is
+    (vis, sigma_vis, amp, sigma_amp, cphase, sigma_cphase, logcamp, sigma_logcamp, flux)."""
+
+    FIELDS = ("vis", "sigma_vis", "amp", "sigma_amp", "cphase", "sigma_cphase", "logcamp",
+              "sigma_logcamp", "flux")
+
+    def __init__(self, vis=None, sigma_vis=None, amp=None, sigma_amp=None, cphase=None,
+                 sigma_cphase=None, logcamp=None, sigma_logcamp=None, flux=None):
+        self.vis, self.sigma_vis = vis, sigma_vis
+        self.amp, self.sigma_amp = amp, sigma_amp
+        self.cphase, self.sigma_cphase = cphase, sigma_cphase
+        self.logcamp, self.sigma_logcamp = logcamp, sigma_logcamp
+        self.flux = flux
+
+    def _map(self, fn):
+        return BlackHoleObservation(**{k: (None if getattr(self, k) is None else fn(getattr(self, k)))
+                                       for k in self.FIELDS})
+
+    def __len__(self):
+        return self.vis.shape[0]
+
+    def __getitem__(self, idx):
+        return self._map(lambda t: t[idx])
+
+    def to(self, device):
+        return self._map(lambda t: t.to(device))
+
+    def detach(self):
+        for k in self.FIELDS:
+            if getattr(self, k) is not None:
+                setattr(self, k, getattr(self, k).detach())
+
+    def to_dict(self):
+        return {k: getattr(self, k) for k in self.FIELDS if getattr(self, k) is not None}
+
+    def to_list(self):
+        return tuple(getattr(self, k) for k in self.FIELDS)
+
+    def from_dict(self, results):
+        for k in self.FIELDS:
+            if k in results:
+                setattr(self, k, results[k])
+        return self
+
+    @classmethod
+    def merge(cls, obs_list):
+        return cls(**{k: torch.cat([getattr(o, k) for o in obs_list], dim=0) for k in cls.FIELDS})
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _LossFn(torch.autograd.Function):
+    """loss[b] with the fused adjoint as its backward (Appendix B of SURVEY.md)."""
+
+    @staticmethod
+    def forward(ctx, x, op, y):
+        need = ctx.needs_input_grad[0]
+        loss, gvis, gflux = op._loss_forward(x.detach(), y, need)
+        ctx.op, ctx.shape, ctx.dtype = op, x.shape, x.dtype
+        if need:
+            ctx.save_for_backward(gvis, gflux)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        gvis, gflux = ctx.saved_tensors
+        g = ctx.op._adjoint(gvis, gflux, _f32(grad_loss, gvis.device), 0.5)
+        return g.view(ctx.shape).to(ctx.dtype), None, None
+
+
+class _VisFn(torch.autograd.Function):
+    """forward_vis (x already in [0,1]) with the DFT adjoint as its backward."""
+
+    @staticmethod
+    def forward(ctx, x, op):
+        vis, _ = op._dft(x.detach(), 1.0, 0.0, _NEG_INF)
+        ctx.op, ctx.shape, ctx.dtype = op, x.shape, x.dtype
+        return vis
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gvis):
+        op = ctx.op
+        gv = torch.view_as_real(gvis.detach().to(torch.complex64).contiguous())
+        gflux = torch.zeros(gv.shape[0], op.T, device=gv.device, dtype=torch.float32)
+        g = op._adjoint(gv, gflux, None, 1.0)
+        return g.view(ctx.shape).to(ctx.dtype), None
+
+
+@register_operator('blackhole')
+class BlackHoleImagingTorch(Operator):
+    def __init__(self, array="configs/task/EHT2017.txt", imsize=256, w_vis=0, w_amp=0,
+                 w_cphase=1, w_logcamp=1, w_flux=0.5, loss_normalize=True, num_frames=64,
+                 ref_multiplier=1.0, device='cuda', obs_table=None, force_dense=False):
+        super().__init__(0)
+        assert num_frames == 64, "num_frames should be 64"
+        table = obs_table if obs_table is not None else eht_lite.eht_table(array)
+        self.ref_multiplier = ref_multiplier
+        self.device = torch.device(device)
+        self.psize = eht_lite.PSIZE
+        uv = np.asarray(table["uv"], dtype=np.float64)
+        T, F = uv.shape[0], uv.shape[1]
+        assert T == num_frames, "observation table has %d frames, num_frames=%d" % (T, num_frames)
+        self.time_list = np.asarray(table["frame_times"])
+        sigma = torch.from_numpy(np.asarray(table["sigma"], dtype=np.float64)).float() / ref_multiplier
+        cp_i, cp_c, ca_i, ca_c = self._closure_tables(table)
+        ey, ex = eht_lite.ft_factors(uv, imsize, imsize, self.psize)
+        self._init_common(T, F, imsize, imsize, sigma, cp_i, cp_c, ca_i, ca_c, w_vis, w_amp,
+                          w_cphase, w_logcamp, w_flux, loss_normalize)
+        sep_ok = (F <= 31 and imsize % 32 == 0 and imsize <= 512)
+        if sep_ok and not force_dense:
+            self._init_sep(ey, ex)
+        else:
+            A = torch.from_numpy(eht_lite.dense_from_factors(ey, ex)).to(torch.complex64)
+            self._init_dense(A.to(self.device))
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_tensors(cls, A_vis, sigma, cp_index, cp_conjugate, camp_index, camp_conjugate,
+                     imsize, w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.5,
+                     loss_normalize=True, device='cuda'):
+        """Operator around an arbitrary dense ``A_vis`` ([1,T,F,H*W] or [T,F,H*W] complex) and
+        the reference's index tensors -- the attributes the reference keeps (blackhole.py:155-163).
+        ``sigma`` is the per-visibility sigma already divided by ref_multiplier."""
+        self = cls.__new__(cls)
+        Operator.__init__(self, 0)
+        self.device = torch.device(device)
+        self.ref_multiplier, self.psize, self.time_list = 1.0, eht_lite.PSIZE, None
+        A = A_vis[0] if A_vis.dim() == 4 else A_vis
+        T, F, HW = A.shape
+        H, W = (imsize, imsize) if isinstance(imsize, int) else imsize
+        assert H * W == HW
+        self._init_common(T, F, H, W, sigma.float(), cp_index, cp_conjugate, camp_index,
+                          camp_conjugate, w_vis, w_amp, w_cphase, w_logcamp, w_flux, loss_normalize)
+        self._init_dense(A.to(device=self.device, dtype=torch.complex64).contiguous())
+        return self
+
+    @staticmethod
+    def _closure_tables(table):
+        """Index mapping of blackhole.py:235-264 through the C ABI (bh_build_closure_tables)."""
+        names = {}
+        ids = lambda seq: np.array([names.setdefault(s, len(names)) for s in seq], dtype=np.int32)
+        t1, t2 = ids(table["t1"]), ids(table["t2"])
+        rt = np.ascontiguousarray(table["times"], dtype=np.float64)
+        tri, quad = table["tri"], table["quad"]
+        tt = np.array([t[0] for t in tri], dtype=np.float64)
+        ts = ids([s for t in tri for s in t[1:]]).reshape(-1, 3)
+        qt = np.array([q[0] for q in quad], dtype=np.float64)
+        qs = ids([s for q in quad for s in q[1:]]).reshape(-1, 4)
+        cp_i = np.zeros((len(tri), 3), np.int64)
+        cp_c = np.zeros_like(cp_i)
+        ca_i = np.zeros((len(quad), 4), np.int64)
+        ca_c = np.zeros_like(ca_i)
+        rc = _lib.lib().bh_build_closure_tables(_lib.ptr(rt), _lib.ptr(t1), _lib.ptr(t2), len(rt),
+                                                _lib.ptr(tt), _lib.ptr(ts), len(tri),
+                                                _lib.ptr(qt), _lib.ptr(qs), len(quad),
+                                                _lib.ptr(cp_i), _lib.ptr(cp_c), _lib.ptr(ca_i),
+                                                _lib.ptr(ca_c))
+        _lib.check(rc, "bh_build_closure_tables")
+        return tuple(torch.from_numpy(a) for a in (cp_i, cp_c, ca_i, ca_c))
+
+    def _init_common(self, T, F, H, W, sigma, cp_i, cp_c, ca_i, ca_c, w_vis, w_amp, w_cphase,
+                     w_logcamp, w_flux, loss_normalize):
+        dev = self.device
+        self.T, self.F, self.H, self.W = T, F, H, W
+        self.sigma = sigma.to(dev).contiguous()                           # [T*F]
+        self.cp_index = cp_i.long().to(dev)
+        self.cp_conjugate = cp_c.long().to(dev)
+        self.camp_index = ca_i.long().to(dev)
+        self.camp_conjugate = ca_c.long().to(dev)
+        # dimensions and weights, blackhole.py:166-180
+        self.amp_dim = F * T
+        self.cphase_dim = self.cp_index.shape[0]
+        self.logcamp_dim = self.camp_index.shape[0]
+        self.flux_dim = T
+        self.weight_vis = w_vis * self.amp_dim
+        self.weight_amp = w_amp * self.amp_dim
+        self.weight_cp = w_cphase * self.cphase_dim
+        self.weight_camp = w_logcamp * self.logcamp_dim
+        self.weight_flux = w_flux * self.flux_dim
+        self.loss_normalize = loss_normalize
+        # device tables for the closure kernels (int32) + transposed incidence (host-built)
+        n_vis = T * F
+        cpi = cp_i.cpu().long().contiguous().numpy()
+        cpc = cp_c.cpu().long().contiguous().numpy()
+        cai = ca_i.cpu().long().contiguous().numpy()
+        cac = ca_c.cpu().long().contiguous().numpy()
+        cp_ptr = np.zeros(n_vis + 1, np.int32)
+        ca_ptr = np.zeros(n_vis + 1, np.int32)
+        cp_ent = np.zeros(max(cpi.size, 1), np.int32)
+        ca_ent = np.zeros(max(cai.size, 1), np.int32)
+        rc = _lib.lib().bh_build_incidence(_lib.ptr(cpi), _lib.ptr(cpc), cpi.shape[0],
+                                           _lib.ptr(cai), _lib.ptr(cac), cai.shape[0], n_vis,
+                                           _lib.ptr(cp_ptr), _lib.ptr(cp_ent), _lib.ptr(ca_ptr),
+                                           _lib.ptr(ca_ent))
+        _lib.check(rc, "bh_build_incidence")
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
+        self._tab_tensors = dict(cp_index=i32(cpi), cp_conj=i32(cpc), camp_index=i32(cai),
+                                 cp_ptr=i32(cp_ptr), cp_ent=i32(cp_ent), ca_ptr=i32(ca_ptr),
+                                 ca_ent=i32(ca_ent))
+        tt = self._tab_tensors
+        self._tab = _lib.bh_tables_t(n_vis, cpi.shape[0], cai.shape[0], T,
+                                     tt["cp_index"].data_ptr(), tt["cp_conj"].data_ptr(),
+                                     tt["camp_index"].data_ptr(), tt["cp_ptr"].data_ptr(),
+                                     tt["cp_ent"].data_ptr(), tt["ca_ptr"].data_ptr(),
+                                     tt["ca_ent"].data_ptr())
+        self._weights = _lib.bh_weights_t(float(self.weight_vis), float(self.weight_amp),
+                                          float(self.weight_cp), float(self.weight_camp),
+                                          float(self.weight_flux), int(bool(loss_normalize)))
+
+    def _init_sep(self, ey, ex):
+        T, F, H, W, dev = self.T, self.F, self.H, self.W, self.device
+        self.path = "sep"
+        self._ey, self._ex = ey, ex                       # fp64 factors (host), for A_vis on demand
+        ey_ri = np.zeros((T, 2, 32, H), np.float32)
+        ex_ri = np.zeros((T, 2, 32, W), np.float32)
+        ey_ri[:, 0, :F], ey_ri[:, 1, :F] = ey.real, ey.imag
+        ex_ri[:, 0, :F], ex_ri[:, 1, :F] = ex.real, ex.imag
+        ey_ri[:, 0, F], ex_ri[:, 0, F] = 1.0, 1.0         # flux row
+        ey_t = np.ascontiguousarray(ey_ri.reshape(T, 64, H).transpose(0, 2, 1))   # [T][H][64]
+        self._ey_t = torch.from_numpy(ey_t).to(dev)
+        self._ey_ri = torch.from_numpy(ey_ri).to(dev)
+        self._ex_ri = torch.from_numpy(ex_ri).to(dev)
+        self._A_vis = None
+
+    def _init_dense(self, A):
+        T, F, HW = A.shape
+        self.path = "dense"
+        self._A_vis = A.unsqueeze(0)                       # [1, T, F, HW] like the reference
+        L = _lib.lib()
+        n = L.bh_dense_packed_floats(T, F, HW)
+        self._a_frag = torch.empty(n, device=self.device, dtype=torch.float32)
+        self._a_rows = torch.empty(n, device=self.device, dtype=torch.float32)
+        rc = L.bh_dense_pack(A.data_ptr(), T, F, HW, self._a_frag.data_ptr(),
+                             self._a_rows.data_ptr(), _lib.stream_of(A))
+        _lib.check(rc, "bh_dense_pack")
+
+    @property
+    def A_vis(self):
+        """[1, T, F, H*W] complex64 (materialised on first access on the separable path)."""
+        if self._A_vis is None:
+            A = eht_lite.dense_from_factors(self._ey, self._ex)
+            self._A_vis = torch.from_numpy(A).to(torch.complex64).unsqueeze(0).to(self.device)
+        return self._A_vis
+
+    # ------------------------------------------------------------------ kernel launches
+    def _video(self, x):
+        x = x.detach().to(device=self.device, dtype=torch.float32)
+        return x.reshape(-1, self.T, self.H * self.W).contiguous()
+
+    def _dft(self, x, scale, shift, clip_min):
+        """-> vis [B, T*F] complex64, flux [B, T] of x' = clip(x*scale+shift)."""
+        xv = self._video(x)
+        B = xv.shape[0]
+        vis = torch.empty(B, self.T * self.F, 2, device=self.device, dtype=torch.float32)
+        flux = torch.empty(B, self.T, device=self.device, dtype=torch.float32)
+        L, st = _lib.lib(), _lib.stream_of(xv)
+        if self.path == "sep":
+            rc = L.bh_dft_fwd_sep(self._ey_t.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                                  self.H, self.W, xv.data_ptr(), B, scale, shift, clip_min,
+                                  vis.data_ptr(), flux.data_ptr(), st)
+        else:
+            HW = self.H * self.W
+            ws = torch.empty(L.bh_dense_fwd_workspace_floats(self.T, self.F, HW, B),
+                             device=self.device, dtype=torch.float32)
+            rc = L.bh_dft_fwd_dense(self._a_frag.data_ptr(), self.T, self.F, HW, xv.data_ptr(), B,
+                                    scale, shift, clip_min, vis.data_ptr(), flux.data_ptr(),
+                                    ws.data_ptr(), st)
+        _lib.check(rc, "bh_dft_fwd_" + self.path)
+        return torch.view_as_complex(vis), flux
+
+    def _adjoint(self, gvis, gflux, chain_scale, out_scale):
+        """gvis [B, T*F, 2] fp32, gflux [B, T] -> grad [B, T, H*W] fp32."""
+        B = gvis.shape[0]
+        grad = torch.empty(B, self.T, self.H * self.W, device=self.device, dtype=torch.float32)
+        L, st = _lib.lib(), _lib.stream_of(grad)
+        cs = None if chain_scale is None else chain_scale.data_ptr()
+        if self.path == "sep":
+            rc = L.bh_dft_adj_sep(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                                  self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
+                                  out_scale, grad.data_ptr(), st)
+        else:
+            rc = L.bh_dft_adj_dense(self._a_rows.data_ptr(), self.T, self.F, self.H * self.W,
+                                    gvis.data_ptr(), gflux.data_ptr(), cs, B, out_scale,
+                                    grad.data_ptr(), st)
+        _lib.check(rc, "bh_dft_adj_" + self.path)
+        return grad
+
+    def _meas(self, y):
+        """bh_meas_t for a BlackHoleObservation (+ the tensors that must outlive the launch)."""
+        keep, ptrs = [], []
+        for k in BlackHoleObservation.FIELDS:
+            t = getattr(y, k)
+            if t is None:
+                ptrs.append(None)
+                continue
+            if k == "vis":
+                t = torch.view_as_real(t.detach().to(self.device, torch.complex64).contiguous())
+            else:
+                t = _f32(t, self.device)
+            keep.append(t)
+            ptrs.append(t.data_ptr())
+        batch = next(getattr(y, k).shape[0] for k in ("cphase", "logcamp", "flux", "vis", "amp")
+                     if getattr(y, k) is not None)
+        return _lib.bh_meas_t(*ptrs, batch), keep
+
+    def _loss_forward(self, x, y, need_grad):
+        vis, flux = self._dft(x, 0.5, 0.5, _NEG_INF)          # unnormalize fused, blackhole.py:738
+        B = vis.shape[0]
+        dev = self.device
+        loss = torch.empty(B, device=dev, dtype=torch.float32)
+        chi2 = torch.empty(B, 5, device=dev, dtype=torch.float32)
+        gvis = torch.empty(B, self.T * self.F, 2, device=dev, dtype=torch.float32) if need_grad else None
+        gflux = torch.empty(B, self.T, device=dev, dtype=torch.float32) if need_grad else None
+        meas, keep = self._meas(y)
+        rc = _lib.lib().bh_closure_loss(vis.data_ptr(), flux.data_ptr(), B, C.byref(self._tab),
+                                        C.byref(meas), C.byref(self._weights), loss.data_ptr(),
+                                        chi2.data_ptr(), _lib.ptr(gvis), _lib.ptr(gflux),
+                                        _lib.stream_of(vis))
+        _lib.check(rc, "bh_closure_loss")
+        self.last_chi2 = chi2        # raw (vis, amp, cphase, logcamp, flux) per chain
+        return loss, gvis, gflux
+
+    def _observe(self, vis):
+        vis = vis.detach().to(self.device, torch.complex64).contiguous()
+        B, M, dev = vis.shape[0], self.T * self.F, self.device
+        f = lambda n: torch.empty(B, n, device=dev, dtype=torch.float32)
+        amp, samp = f(M), f(M)
+        cp, scp = f(self.cphase_dim), f(self.cphase_dim)
+        lc, slc = f(self.logcamp_dim), f(self.logcamp_dim)
+        rc = _lib.lib().bh_closure_observe(vis.data_ptr(), self.sigma.data_ptr(), B,
+                                           C.byref(self._tab), amp.data_ptr(), samp.data_ptr(),
+                                           cp.data_ptr(), scp.data_ptr(), lc.data_ptr(),
+                                           slc.data_ptr(), _lib.stream_of(vis))
+        _lib.check(rc, "bh_closure_observe")
+        return amp, samp, cp, scp, lc, slc
+
+    # ------------------------------------------------------------------ reference API
+    # 1. visibility and flux from image x in range [0,1]  (blackhole.py:314-329)
+    def forward_vis(self, x):
+        return _VisFn.apply(x, self)
+
+    def forward_amp(self, x):
+        return self.forward_amp_from_vis(self.forward_vis(x))
+
+    def forward_flux(self, x):
+        return x.flatten(2).sum(-1)
+
+    # 2. forward from visibilities  (blackhole.py:331-401)
+    def correct_vis_direction(self, vis, conj):
+        return vis * (1 - conj) + vis.conj() * conj
+
+    def forward_amp_from_vis(self, vis):
+        amp = vis.abs()
+        return amp, self.sigma + 0 * amp
+
+    def forward_cp_from_vis(self, vis):
+        _, _, cp, scp, _, _ = self._observe(vis)
+        return cp, scp
+
+    def forward_logcamp_from_vis(self, vis):
+        _, _, _, _, lc, slc = self._observe(vis)
+        return lc, slc
+
+    def forward_from_vis(self, x):
+        vis, flux = self._dft(x, 1.0, 0.0, _NEG_INF)
+        amp, samp, cp, scp, lc, slc = self._observe(vis)
+        return BlackHoleObservation(vis, samp, amp, samp, cp, scp, lc, slc, flux)
+
+    # 4. chi-square evaluation  (blackhole.py:447-491)
+    def chi2_vis(self, x, y_vis, y_vis_sigma):
+        return self.chi2_vis_from_meas(self.forward_vis(x), y_vis, y_vis_sigma)
+
+    @staticmethod
+    def chi2_vis_from_meas(y_vis_meas, y_vis, y_vis_sigma):
+        return torch.mean(torch.square(torch.abs(y_vis_meas - y_vis) / y_vis_sigma), dim=1) / 2
+
+    def chi2_amp(self, x, y_amp, y_amp_sigma):
+        return self.chi2_amp_from_meas(self.forward_amp(x)[0], y_amp, y_amp_sigma)
+
+    @staticmethod
+    def chi2_amp_from_meas(y_amp_meas, y_amp, y_amp_sigma):
+        return torch.mean(torch.square((y_amp_meas - y_amp) / y_amp_sigma), dim=1)
+
+    def chi2_cphase(self, x, y_cphase, y_cphase_sigma):
+        cp, _ = self.forward_cp_from_vis(self.forward_vis(x))
+        return self.chi2_cphase_from_meas(cp, y_cphase, y_cphase_sigma)
+
+    @staticmethod
+    def chi2_cphase_from_meas(y_cphase_meas, y_cphase, y_cphase_sigma):
+        return 2. * torch.mean((1 - torch.cos(y_cphase - y_cphase_meas)) / torch.square(y_cphase_sigma), dim=1)
+
+    def chi2_logcamp(self, x, y_camp, y_logcamp_sigma):
+        lc, _ = self.forward_logcamp_from_vis(self.forward_vis(x))
+        return self.chi2_logcamp_from_meas(lc, y_camp, y_logcamp_sigma)
+
+    @staticmethod
+    def chi2_logcamp_from_meas(y_logcamp_meas, y_logcamp, y_logcamp_sigma):
+        return torch.mean(torch.abs((y_logcamp_meas - y_logcamp) / y_logcamp_sigma) ** 2, dim=1)
+
+    def chi2_flux(self, x, y_flux):
+        return self.chi2_flux_from_meas(self.forward_flux(x), y_flux)
+
+    @staticmethod
+    def chi2_flux_from_meas(y_flux_meas, y_flux):
+        return torch.mean(torch.square((y_flux_meas - y_flux) / 2), dim=1)
+
+    # 8. evaluating chi-square  (blackhole.py:664-699)
+    @staticmethod
+    def normalize_chisq(chisq):
+        overfit = chisq < 1.0
+        return chisq * (~overfit) + 1 / chisq * overfit
+
+    def evaluate_chisq(self, x, y, normalize=False, chi_sq_list=['vis', 'amp', 'cphase', 'logcamp']):
+        # clip(min=0) fused into the DFT load; the per-frame flux alignment is linear in the DFT,
+        # so it is applied to the visibilities (vis_scale) instead of re-running it on x * ratio
+        vis, x_flux = self._dft(x, 0.5, 0.5, 0.0)
+        B = vis.shape[0]
+        scale = (_f32(y.flux, self.device) / x_flux).contiguous()
+        chi2 = torch.empty(B, 4, device=self.device, dtype=torch.float32)
+        meas, keep = self._meas(y)
+        rc = _lib.lib().bh_closure_chisq(torch.view_as_real(vis).data_ptr(), scale.data_ptr(), B,
+                                         self.F, C.byref(self._tab), C.byref(meas),
+                                         chi2.data_ptr(), _lib.stream_of(vis))
+        _lib.check(rc, "bh_closure_chisq")
+        results = {}
+        for i, k in enumerate(('vis', 'amp', 'cphase', 'logcamp')):
+            if k in chi_sq_list:
+                v = chi2[:, i]
+                results[k] = self.normalize_chisq(v) if normalize else v
+        return results
+
+    # 9. public interface  (blackhole.py:719-771)
+    def unnormalize(self, inputs):
+        return inputs * 0.5 + 0.5
+
+    def normalize(self, inputs):
+        return inputs * 2 - 1
+
+    def __call__(self, x, **kwargs):
+        vis, flux = self._dft(x, 0.5, 0.5, _NEG_INF)
+        amp, samp, cp, scp, lc, slc = self._observe(vis)
+        return BlackHoleObservation(vis, samp, amp, samp, cp, scp, lc, slc, flux)
+
+    def measure(self, x, **kwargs):
+        raise NotImplementedError(
+            "measure() synthesises noisy EHT data with ehtim.observe_same in the reference "
+            "(blackhole.py:494-586); ehtim is not available to this build. Use op(x) for the "
+            "noiseless observation or step_amd.forward_operator.blackhole.thermal_measure().")
+
+    def loss(self, x, y):
+        return _LossFn.apply(x, self, y)
+
+    def gradient(self, x, y, return_loss=False):
+        """Fused loss forward + adjoint (no autograd graph); same result as the base class's
+        autograd.grad of loss(x, y).sum()  (base.py:43-49)."""
+        loss, gvis, gflux = self._loss_forward(x, y, True)
+        grad = self._adjoint(gvis, gflux, None, 0.5).view(x.shape).to(x.dtype)
+        if return_loss:
+            return grad, loss.sum()
+        return grad
+
+
+def thermal_measure(op, x, generator=None):
+    """Noisy observation WITHOUT ehtim (no reference counterpart for the noise model): complex
+    Gaussian thermal noise of std ``op.sigma`` on the visibilities, data products recomputed."""
+    clean = op(x)
+    n = torch.randn(clean.vis.shape + (2,), device=clean.vis.device, generator=generator)
+    vis = clean.vis + op.sigma * torch.view_as_complex(n)
+    amp, samp, cp, scp, lc, slc = op._observe(vis)
+    return BlackHoleObservation(vis, samp, amp, samp, cp, scp, lc, slc, clean.flux)

@@ -1,0 +1,147 @@
+"""Dynamic-MRI operator on MI355X kernels behind the reference's interface
+(reference forward_operator/dynamic_mri.py): registry name ``'mri'``, constructor kwargs
+``acc_factor, mode, resolution, frames, num_acs_lines, sigma``, ``self.mask`` of the
+reference's shape, ``__call__`` = M * FFT2(fftshift(x_re + i x_im)).
+
+``loss`` / ``gradient`` (inherited semantics of base.py:40-49) run the fused
+forward + residual + adjoint kernel: one launch per Langevin step."""
+import numpy as np
+import torch
+
+from .. import _lib
+from .base import Operator, register_operator
+
+__all__ = ["DynamicMRI"]
+
+_MODES = {"same_mask": 0, "split_mask": 1, "random_split_mask": 2}
+
+
+def _f32c(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _ForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        ctx.op, ctx.dtype = op, x.dtype
+        return op._launch_forward(_f32c(x, x.device))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return ctx.op._launch_adjoint(_f32c(g, g.device)).to(ctx.dtype), None
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, y):
+        need = ctx.needs_input_grad[0]
+        loss, grad = op._launch_loss_grad(_f32c(x, x.device), y, need, None)
+        ctx.dtype = x.dtype
+        if need:
+            ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        g = grad * grad_loss.to(grad.dtype).view(-1, 1, 1, 1, 1)
+        return g.to(ctx.dtype), None, None
+
+
+@register_operator('mri')
+class DynamicMRI(Operator):
+    def __init__(self, acc_factor, mode='same_mask', resolution=192, frames=12, num_acs_lines=12,
+                 sigma=0):
+        super().__init__(sigma)
+        self.acc_factor = acc_factor
+        if mode not in _MODES:
+            raise ValueError('Unknown mode: {}'.format(mode))
+        self.mode, self.resolution, self.frames = mode, resolution, frames
+        mf = 1 if mode == 'same_mask' else frames
+        m = np.zeros((mf, resolution), np.float32)
+        rc = _lib.lib().mri_build_mask(int(acc_factor), _MODES[mode], int(resolution), int(frames),
+                                       int(num_acs_lines), _lib.ptr(m))
+        _lib.check(rc, "mri_build_mask")
+        # reference layout: [1, 1 or T, 1, H, 1] float32 (dynamic_mri.py:15,24,35)
+        self.mask = torch.from_numpy(m).view(1, mf, 1, resolution, 1)
+        rows = np.full((mf, resolution), -1, np.int32)
+        nrows = np.zeros(mf, np.int32)
+        for f in range(mf):
+            kept = np.nonzero(m[f])[0].astype(np.int32)
+            rows[f, :len(kept)] = kept
+            nrows[f] = len(kept)
+        self._rows_host, self._nrows_host = rows, nrows
+        self._max_rows = int(nrows.max())
+        self._dev_tables = {}
+
+    def _tables(self, device):
+        key = str(device)
+        if key not in self._dev_tables:
+            self._dev_tables[key] = (torch.from_numpy(self._rows_host).to(device),
+                                     torch.from_numpy(self._nrows_host).to(device))
+        return self._dev_tables[key]
+
+    def _dims(self, x):
+        if x.dim() != 5 or x.shape[2] != 2 or x.shape[3] != self.resolution \
+                or x.shape[4] != self.resolution:
+            raise ValueError("mri operator expects [B, T, 2, %d, %d], got %s"
+                             % (self.resolution, self.resolution, tuple(x.shape)))
+        mf = self.mask.shape[1]
+        if mf != 1 and x.shape[1] != mf:
+            raise ValueError("mask has %d frames, input has %d" % (mf, x.shape[1]))
+        return x.shape[0], x.shape[1]
+
+    def _launch_forward(self, x):
+        B, T = self._dims(x)
+        rows, nrows = self._tables(x.device)
+        out = torch.empty_like(x)
+        rc = _lib.lib().mri_forward(x.data_ptr(), B, T, self.resolution, rows.data_ptr(),
+                                    nrows.data_ptr(), self.mask.shape[1], self._max_rows,
+                                    out.data_ptr(), _lib.stream_of(x))
+        _lib.check(rc, "mri_forward")
+        return out
+
+    def _launch_adjoint(self, g):
+        B, T = self._dims(g)
+        rows, nrows = self._tables(g.device)
+        out = torch.empty_like(g)
+        rc = _lib.lib().mri_adjoint(g.data_ptr(), B, T, self.resolution, rows.data_ptr(),
+                                    nrows.data_ptr(), self.mask.shape[1], self._max_rows,
+                                    out.data_ptr(), _lib.stream_of(g))
+        _lib.check(rc, "mri_adjoint")
+        return out
+
+    def _launch_loss_grad(self, x, y, need_grad, chain_scale):
+        B, T = self._dims(x)
+        y = _f32c(y, x.device)
+        if y.dim() != 5 or y.shape[1:] != x.shape[1:] or y.shape[0] not in (1, B):
+            raise ValueError("measurement shape %s does not match input %s"
+                             % (tuple(y.shape), tuple(x.shape)))
+        rows, nrows = self._tables(x.device)
+        part = torch.empty(B * T, device=x.device, dtype=torch.float32)
+        loss = torch.empty(B, device=x.device, dtype=torch.float32)
+        grad = torch.empty_like(x) if need_grad else None
+        rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
+                                      self.resolution, rows.data_ptr(), nrows.data_ptr(),
+                                      self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
+                                      part.data_ptr(), loss.data_ptr(), _lib.ptr(grad),
+                                      _lib.stream_of(x))
+        _lib.check(rc, "mri_loss_grad")
+        return loss, grad
+
+    # ------------------------------------------------------------------ reference API
+    def __call__(self, x):
+        # [B, T, C, H, W] -> masked k-space, same layout (dynamic_mri.py:42-48)
+        return _ForwardFn.apply(x, self)
+
+    def loss(self, x, y):
+        return _LossFn.apply(x, self, y)
+
+    def gradient(self, x, y, return_loss=False):
+        loss, grad = self._launch_loss_grad(_f32c(x, x.device), y, True, None)
+        grad = grad.to(x.dtype)
+        if return_loss:
+            return grad, loss.sum()
+        return grad

@@ -1,0 +1,296 @@
+"""DAPS sampling loop behind the reference's interface (reference sampler/daps.py).
+
+``MCMCSampler`` is the hot inner loop (daps.py:76-251): per step one fused operator
+gradient (HIP kernels via ``operator.gradient``) and one fused state-update kernel
+(``mcmc_update``) replacing ~10 elementwise launches and the per-step NaN host sync.
+``LatentDAPS`` is the annealing driver around it (daps.py:254-382); the denoiser / VAE it
+calls stay stock PyTorch.  Noise is drawn with ``torch.randn_like`` in the reference's order,
+so a shared generator state reproduces the reference's random stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..forward_operator.latent_wrapper import LatentWrapper
+from .base import register_sampler
+from .schedule import get_diffusion_scheduler, pfode_euler
+
+__all__ = ["Trajectory", "MCMCSampler", "LatentDAPS"]
+
+
+class Trajectory(nn.Module):
+    """Recorder for intermediate states (daps.py:10-73)."""
+
+    def __init__(self):
+        super().__init__()
+        self.tensor_data, self.value_data, self._compile = {}, {}, False
+
+    def add_tensor(self, name, images):
+        self.tensor_data.setdefault(name, []).append(images.detach().cpu())
+
+    def add_value(self, name, values):
+        self.value_data.setdefault(name, []).append(values)
+
+    def compile(self):
+        if not self._compile:
+            self._compile = True
+            self.tensor_data = {k: torch.stack(v, dim=0) for k, v in self.tensor_data.items()}
+            self.value_data = {k: torch.tensor(v) for k, v in self.value_data.items()}
+        return self
+
+    @classmethod
+    def merge(cls, trajs):
+        out = cls()
+        for name in trajs[0].tensor_data.keys():
+            out.tensor_data[name] = torch.cat([t.tensor_data[name] for t in trajs], dim=1)
+        for name in trajs[0].value_data.keys():
+            out.value_data[name] = trajs[0].value_data[name]
+        return out
+
+
+class MCMCSampler(nn.Module):
+    """Langevin / damped-HMC / Metropolis-Hastings inner loop.
+
+    ``nan_check``: 'deferred' (default) keeps the NaN guard of daps.py:202-203 on the device and
+    reads it once after the last step -- the returned tensor is identical (a NaN state stays NaN,
+    the whole batch comes back as zeros) but no host synchronisation happens per step;
+    'step' reads it every step and returns early exactly like the reference."""
+
+    def __init__(self, num_steps, lr, tau=0.01, lr_min_ratio=0.01, prior_solver='gaussian',
+                 prior_sigma_min=1e-2, mc_algo='langevin', momentum=0.9, nan_check='deferred'):
+        super().__init__()
+        self.num_steps = num_steps
+        self.lr = lr
+        self.tau = tau
+        self.lr_min_ratio = lr_min_ratio
+        self.prior_solver = prior_solver
+        self.prior_sigma_min = prior_sigma_min
+        self.mc_algo = mc_algo
+        self.momentum = momentum
+        assert nan_check in ('deferred', 'step')
+        self.nan_check = nan_check
+
+    # ------------------------------------------------------------------ reference-shaped pieces
+    def score_fn(self, x, x0hat, model, xt, operator, measurement, sigma):
+        """score of p(x_0 = x | x_t, y) as separate torch ops (daps.py:93-104); the sampling loop
+        uses the fused kernel instead, this stays for callers of the reference API."""
+        g, loss = operator.gradient(x, measurement, return_loss=True)
+        data_term = -g / self.tau ** 2
+        xt_term = (xt - x) / sigma ** 2
+        return data_term + xt_term + self.get_prior_score(x, x0hat, xt, model, sigma), loss
+
+    def get_prior_score(self, x, x0hat, xt, model, sigma):
+        if self.prior_solver in ('score-min', 'score-t', 'gaussian'):
+            return self.prior_score
+        if self.prior_solver == 'exact':
+            return model.score(x, torch.tensor(self.prior_sigma_min).to(x.device)).detach()
+        raise NotImplementedError
+
+    def prepare_prior_score(self, x0hat, xt, model, sigma):
+        if self.prior_solver == 'score-min':
+            self.prior_score = model.score(x0hat, self.prior_sigma_min).detach()
+        elif self.prior_solver == 'score-t':
+            self.prior_score = model.score(xt, sigma).detach()
+        elif self.prior_solver == 'gaussian':
+            self.prior_score = (x0hat - xt).detach() / sigma ** 2
+        elif self.prior_solver != 'exact':
+            raise NotImplementedError
+
+    def mc_prepare(self, x0hat, xt, model, operator, measurement, sigma):
+        if self.mc_algo == 'hmc':
+            self.velocity = torch.randn_like(x0hat)
+
+    def mc_update(self, x, cur_score, lr, epsilon):
+        """Unfused update (daps.py:135-144), kept for callers of the reference API."""
+        if self.mc_algo == 'langevin':
+            return x + lr * cur_score + np.sqrt(2 * lr) * epsilon
+        if self.mc_algo == 'hmc':
+            step_size = np.sqrt(lr)
+            self.velocity = self.momentum * self.velocity + step_size * cur_score \
+                + np.sqrt(2 * (1 - self.momentum)) * epsilon
+            return x + self.velocity * step_size
+        raise NotImplementedError
+
+    def get_lr(self, ratio):
+        p = 1
+        multiplier = (1 ** (1 / p) + ratio * (self.lr_min_ratio ** (1 / p) - 1 ** (1 / p))) ** p
+        return multiplier * self.lr
+
+    # ------------------------------------------------------------------ fused step
+    def _params(self, lr, sigma):
+        algo = {'langevin': 0, 'hmc': 1}.get(self.mc_algo)
+        if algo is None:
+            raise NotImplementedError
+        return _lib.mcmc_params_t(1.0 / self.tau ** 2, 1.0 / float(sigma) ** 2, lr, np.sqrt(lr),
+                                  np.sqrt(2 * lr), self.momentum,
+                                  np.sqrt(2 * (1 - self.momentum)), algo)
+
+    @staticmethod
+    def _kernel_tensor(t, like):
+        if t.device.type != 'cuda':
+            raise RuntimeError("step_amd MCMCSampler runs on the GPU only (tensor on %s)" % t.device)
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != like.shape:
+            t = t.to(torch.float32).expand_as(like).contiguous()
+        return t
+
+    def _fused_update(self, x, grad, xt, prior, eps, params, nan_flag):
+        """In place on x (and self.velocity): score_fn + mc_update + NaN flag in one launch."""
+        vel = self.velocity if self.mc_algo == 'hmc' else None
+        rc = _lib.lib().mcmc_update(x.data_ptr(), _lib.ptr(vel), grad.data_ptr(), xt.data_ptr(),
+                                    _lib.ptr(prior), eps.data_ptr(), x.numel(), C.byref(params),
+                                    nan_flag.data_ptr(), _lib.stream_of(x))
+        _lib.check(rc, "mcmc_update")
+
+    # ------------------------------------------------------------------ samplers
+    def sample(self, xt, model, x0hat, operator, measurement, sigma, ratio, record=False,
+               verbose=False):
+        if self.mc_algo == 'MH':
+            return self.sample_MH(xt, model, x0hat, operator, measurement, sigma, ratio, record, verbose)
+        if record:
+            self.trajectory = Trajectory()
+        lr = self.get_lr(ratio)
+        self.mc_prepare(x0hat, xt, model, operator, measurement, sigma)
+        self.prepare_prior_score(x0hat, xt, model, sigma)
+
+        x = x0hat.clone().detach()
+        if x.dtype != torch.float32:
+            raise TypeError("step_amd MCMCSampler needs a float32 state, got %s" % x.dtype)
+        x = x.contiguous()
+        xt_k = self._kernel_tensor(xt.detach(), x)
+        if self.mc_algo == 'hmc':
+            self.velocity = self._kernel_tensor(self.velocity, x)
+        params = self._params(lr, sigma)
+        nan_flag = torch.zeros(1, device=x.device, dtype=torch.int32)
+        for _ in range(self.num_steps):
+            grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
+            prior = self.get_prior_score(x, x0hat, xt, model, sigma)
+            epsilon = torch.randn_like(x)
+            self._fused_update(x, self._kernel_tensor(grad, x), xt_k,
+                               self._kernel_tensor(prior, x), epsilon, params, nan_flag)
+            if self.nan_check == 'step' and nan_flag.item():
+                return torch.zeros_like(x)
+            if record:
+                self._record(x.clone(), epsilon, fitting_loss.sqrt())
+        if self.nan_check == 'deferred' and nan_flag.item():
+            return torch.zeros_like(x)
+        return x.detach()
+
+    def sample_MH(self, xt, model, x0hat, operator, measurement, sigma, ratio, record=False,
+                  verbose=False):
+        if record:
+            self.trajectory = Trajectory()
+        lr = self.get_lr(ratio)
+        x = x0hat.clone().detach()
+        for _ in range(self.num_steps):
+            x_new = x + torch.randn_like(x) * np.sqrt(lr)
+            loss_new = operator.loss(x_new, measurement)
+            loss_old = operator.loss(x, measurement)
+            log_data_ratio = (loss_old - loss_new) / (2 * self.tau ** 2)
+            prior_new = (x_new - x0hat).pow(2).flatten(1).sum(-1)
+            prior_old = (x - x0hat).pow(2).flatten(1).sum(-1)
+            log_accept = log_data_ratio + (prior_old - prior_new) / (2 * sigma ** 2)
+            accept = torch.rand_like(log_accept).log() < log_accept
+            x = torch.where(accept.view(-1, *[1] * len(x.shape[1:])), x_new, x)
+        return x.detach()
+
+    def optimize(self, x0hat, operator, measurement, sigma, ratio, record=False, verbose=False):
+        lr = self.get_lr(ratio)
+        x = x0hat.clone().detach()
+        for _ in range(self.num_steps):
+            g, loss = operator.gradient(x, measurement, return_loss=True)
+            x = x - lr * (g + (x - x0hat.detach()) / sigma ** 2)
+            if record:
+                self._record(x, g, loss)
+        return x.detach()
+
+    def _record(self, x, epsilon, loss):
+        self.trajectory.add_tensor('xi', x)
+        self.trajectory.add_tensor('epsilon', epsilon)
+        self.trajectory.add_value('loss', loss)
+
+    def summary(self):
+        print('+' * 50)
+        print('MCMC Sampler Summary (step_amd fused kernels)')
+        print('+' * 50)
+        for k, v in (("Prior Solver", self.prior_solver), ("MCMC Algorithm", self.mc_algo),
+                     ("Num Steps", self.num_steps), ("Learning Rate", self.lr), ("Tau", self.tau),
+                     ("LR Min Ratio", self.lr_min_ratio)):
+            print(f"{k:<16}: {v}")
+        print('+' * 50)
+
+
+@register_sampler('latent_daps')
+class LatentDAPS(nn.Module):
+    """Latent decoupled annealing posterior sampling (daps.py:254-382): per annealing step a
+    PF-ODE denoise (stock PyTorch prior), the MCMC data-consistency loop above, and re-noising."""
+
+    def __init__(self, annealing_scheduler_config, diffusion_scheduler_config, mcmc_sampler_config,
+                 latent_wrapper=True, batch_consistency=False):
+        super().__init__()
+        diffusion_scheduler_config = dict(diffusion_scheduler_config)
+        diffusion_scheduler_config.pop('sigma_max', None)      # changes every step (daps.py:355-363)
+        self.annealing_scheduler = get_diffusion_scheduler(**annealing_scheduler_config)
+        self.diffusion_scheduler_config = diffusion_scheduler_config
+        self.mcmc_sampler = MCMCSampler(**mcmc_sampler_config)
+        self.batch_consistency = batch_consistency
+        self.latent_wrapper = latent_wrapper
+
+    def get_randn_like(self, ref):
+        if self.batch_consistency:
+            return torch.randn_like(ref[:, 0]).unsqueeze(1).expand_as(ref)
+        return torch.randn_like(ref)
+
+    def sample(self, model, z_start, operator, measurement, evaluator=None, record=False,
+               verbose=False, **kwargs):
+        if record:
+            self.trajectory = Trajectory()
+        sched = self.annealing_scheduler
+        wrapped = LatentWrapper(operator, model) if self.latent_wrapper else operator
+        zt = z_start
+        for step in range(sched.num_steps - 1):
+            sigma = sched.sigma_steps[step]
+            with torch.no_grad():
+                ds = get_diffusion_scheduler(**self.diffusion_scheduler_config, sigma_max=sigma)
+                z0hat = pfode_euler(model, ds, zt)
+                x0hat = model.decode(z0hat)
+            ratio = step / sched.num_steps
+            if self.latent_wrapper:
+                z0y = self.mcmc_sampler.sample(zt, model, z0hat, wrapped, measurement, sigma, ratio)
+                with torch.no_grad():
+                    x0y = model.decode(z0y)
+            else:
+                x0y = self.mcmc_sampler.optimize(x0hat, operator, measurement, sigma, ratio)
+                z0y = model.encode(x0y)
+            # step < num_steps - 1 always holds here, as in the reference (daps.py:316-319)
+            zt = z0y + self.get_randn_like(z0y) * sched.sigma_steps[step + 1]
+            x0hat_results = x0y_results = {}
+            if evaluator and 'gt' in kwargs:
+                with torch.no_grad():
+                    x0hat_results = evaluator(kwargs['gt'], measurement, x0hat)
+                    x0y_results = evaluator(kwargs['gt'], measurement, x0y)
+            if record:
+                self._record(model.decode(zt), x0y, x0hat, sigma, x0hat_results, x0y_results)
+        return model.decode(zt)
+
+    def _record(self, xt, x0y, x0hat, sigma, x0hat_results, x0y_results):
+        self.trajectory.add_tensor('xt', xt)
+        self.trajectory.add_tensor('x0y', x0y)
+        self.trajectory.add_tensor('x0hat', x0hat)
+        self.trajectory.add_value('sigma', sigma)
+        for name, v in x0hat_results.items():
+            self.trajectory.add_value(f'x0hat_{name}', v)
+        for name, v in x0y_results.items():
+            self.trajectory.add_value(f'x0y_{name}', v)
+
+    def get_start(self, ref):
+        return self.get_randn_like(ref) * self.annealing_scheduler.sigma_max
+
+    def summary(self):
+        print('Annealing Scheduler: edm, %d steps, sigma %g -> %g'
+              % (self.annealing_scheduler.num_steps - 1, self.annealing_scheduler.sigma_max,
+                 self.annealing_scheduler.sigma_min))
+        print('MCMC Sampler:')
+        self.mcmc_sampler.summary()

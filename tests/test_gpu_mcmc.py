@@ -1,0 +1,94 @@
+"""GPU parity tests of the MCMC inner loop (fused update kernel + operator kernels) against
+trajectories recorded from the reference's MCMCSampler (tests/golden/mcmc_bh_small.npz).
+The reference's noise draws are replayed so that the comparison is deterministic."""
+import pytest
+import torch
+
+from tests.helpers import RTOL, assert_close, t
+from tests.test_gpu_blackhole import make_dense_op, make_y
+from tests.toy_model import ToyModel
+
+pytestmark = pytest.mark.gpu
+
+# a few steps of a stiff chain amplify the 1e-7 rounding differences of each step
+TRAJ_TOL = 5 * RTOL
+
+
+class Replay:
+    """Feeds recorded torch.randn_like / rand_like draws back in order."""
+
+    def __init__(self, normals, uniforms=None):
+        self.n, self.u = list(normals), list(uniforms or [])
+        self._rn, self._ru = torch.randn_like, torch.rand_like
+
+    def __enter__(self):
+        torch.randn_like = lambda ref, *a, **k: self.n.pop(0).to(ref.device).reshape(ref.shape)
+        torch.rand_like = lambda ref, *a, **k: self.u.pop(0).to(ref.device).reshape(ref.shape)
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like, torch.rand_like = self._rn, self._ru
+
+
+CASES = {
+    "hmc_exact_latent": (dict(num_steps=6, lr=1.2e-5, tau=0.021, lr_min_ratio=0.015,
+                              prior_solver="exact", mc_algo="hmc", momentum=0.0), "latent"),
+    "hmc_mom_gauss_latent": (dict(num_steps=6, lr=1.2e-3, tau=0.5, lr_min_ratio=0.011,
+                                  prior_solver="gaussian", mc_algo="hmc", momentum=0.83), "latent"),
+    "langevin_scoret_latent": (dict(num_steps=5, lr=1e-4, tau=0.3, prior_solver="score-t",
+                                    mc_algo="langevin"), "latent"),
+    "langevin_scoremin_pixel": (dict(num_steps=4, lr=1e-6, tau=1.0, prior_solver="score-min",
+                                     mc_algo="langevin"), "pixel"),
+}
+
+
+@pytest.fixture(scope="module")
+def setup(golden, dev):
+    g, m = golden("bh_small"), golden("mcmc_bh_small")
+    return dict(op=make_dense_op(g, dev), y=make_y(g, dev), m=m,
+                model=ToyModel((64, 1, 8, 8), factor=2, gain=1.5).to(dev))
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("nan_check", ["deferred", "step"])
+def test_sample_matches_reference_trajectory(case, nan_check, setup, dev):
+    from step_amd.forward_operator import LatentWrapper
+    from step_amd.sampler import MCMCSampler
+    cfg, space = CASES[case]
+    m, op, y, model = setup["m"], setup["op"], setup["y"], setup["model"]
+    sampler = MCMCSampler(nan_check=nan_check, **cfg)
+    assert sampler.get_lr(float(m["ratio"])) == float(m[case + "_lr"])
+    if space == "latent":
+        oper, start, xt = LatentWrapper(op, model), t(m["z0hat"], dev), t(m["zt"], dev)
+    else:
+        oper, start, xt = op, t(m["x0hat"], dev), t(m[case + "_xt"], dev)
+    with Replay(list(t(m[case + "_noise"]))):
+        out = sampler.sample(xt, model, start, oper, y, float(m["sigma"]), float(m["ratio"]),
+                             record=True)
+    traj = sampler.trajectory.compile().tensor_data["xi"]
+    assert_close(traj, m[case + "_traj"], TRAJ_TOL, case + " trajectory")
+    assert_close(out, m[case + "_result"], TRAJ_TOL, case + " result")
+
+
+def test_metropolis_hastings_and_optimize(setup, dev):
+    from step_amd.sampler import MCMCSampler
+    m, op, y, model = setup["m"], setup["op"], setup["y"], setup["model"]
+    x0hat, sigma, ratio = t(m["x0hat"], dev), float(m["sigma"]), float(m["ratio"])
+    s = MCMCSampler(num_steps=6, lr=1e-7, tau=3.0, mc_algo="MH")
+    with Replay(list(t(m["mh_pixel_noise"])), list(t(m["mh_pixel_unif"]))):
+        out = s.sample(t(m["mh_pixel_xt"], dev), model, x0hat, op, y, sigma, ratio)
+    assert_close(out, m["mh_pixel_result"], TRAJ_TOL, "MH result")
+    o = MCMCSampler(num_steps=5, lr=2e-7, tau=1.0).optimize(x0hat, op, y, sigma, ratio)
+    assert_close(o, m["optimize_result"], TRAJ_TOL, "optimize result")
+
+
+def test_nan_guard_returns_zeros(setup, dev):
+    """daps.py:202-203: any NaN in the state -> the whole batch comes back as zeros."""
+    from step_amd.sampler import MCMCSampler
+    m, op, y, model = setup["m"], setup["op"], setup["y"], setup["model"]
+    x0hat = t(m["x0hat"], dev).clone()
+    x0hat[1, 3, 0, 2, 2] = float("nan")
+    for mode in ("deferred", "step"):
+        s = MCMCSampler(num_steps=3, lr=1e-6, tau=1.0, prior_solver="gaussian", nan_check=mode)
+        out = s.sample(x0hat, model, x0hat, op, y, 0.7, 0.25)
+        assert out.shape == x0hat.shape and torch.count_nonzero(out).item() == 0

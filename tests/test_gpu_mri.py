@@ -1,0 +1,118 @@
+"""GPU parity tests of the fused dynamic-MRI kernels (through the C ABI) against the golden
+fixtures generated from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.mri_oracle import MRIOracle
+from tests.helpers import RTOL, assert_close, t
+
+pytestmark = pytest.mark.gpu
+
+
+def inputs(g):
+    rng = np.random.RandomState(int(g["seed"]))
+    B = int(g["B"])
+    shape = (B, 12, 2, 192, 192)
+    x_gt = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+    x = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+    nz = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+    return x_gt, x, nz
+
+
+def make_op(mode, **kw):
+    from step_amd.forward_operator import get_operator
+    cfg = dict(acc_factor=6, mode=mode, resolution=192, frames=12, num_acs_lines=24)
+    cfg.update(kw)
+    return get_operator("mri", **cfg)
+
+
+@pytest.mark.parametrize("mode", ["same_mask", "split_mask", "random_split_mask"])
+def test_matches_golden(mode, golden, dev):
+    g = golden("mri_" + mode)
+    op = make_op(mode, sigma=float(g["noise"]))
+    assert np.array_equal(op.mask[0, :, 0, :, 0].numpy().astype(np.uint8), g["mask"])
+    x_gt, x, nz = inputs(g)
+    y = op(x_gt.to(dev)) + float(g["noise"]) * nz.to(dev)
+    fwd = op(x.to(dev))
+    scale = float(np.abs(g["fwd_sub"]).max())
+    assert (fwd.cpu().flatten()[::11] - t(g["fwd_sub"])).abs().max().item() <= RTOL * scale
+    assert_close(fwd[0, 0], g["fwd_frame0"], RTOL, "forward frame 0")
+    assert_close((fwd.double() ** 2).flatten(1).sum(-1), g["fwd_sq_sum"], RTOL, "forward energy")
+    grad, lsum = op.gradient(x.to(dev), y, return_loss=True)
+    gscale = float(np.abs(g["grad_sub"]).max())
+    assert (grad.cpu().flatten()[::11] - t(g["grad_sub"])).abs().max().item() <= RTOL * gscale
+    assert_close(grad[0, 0], g["grad_frame0"], RTOL, "gradient frame 0")
+    assert_close((grad.double() ** 2).flatten(1).sum(-1), g["grad_sq_sum"], RTOL, "gradient energy")
+    assert_close(lsum, g["loss_sum"], RTOL, "loss sum")
+    assert_close(op.loss(x.to(dev), y), g["loss"], RTOL, "loss")
+
+
+@pytest.mark.parametrize("mode,acc,acs", [("same_mask", 6, 24), ("split_mask", 8, 12),
+                                          ("random_split_mask", 6, 24), ("same_mask", 2, 24),
+                                          ("same_mask", 1, 0), ("split_mask", 1, 0)])
+def test_matches_oracle(mode, acc, acs, dev):
+    """Includes masks with more kept rows than the LDS row buffer (acc 2: 108 rows, acc 1: all
+    192) which run in row groups with gradient accumulation."""
+    op = make_op(mode, acc_factor=acc, num_acs_lines=acs)
+    orc = MRIOracle(acc, mode, 192, 12, acs)
+    assert torch.equal(op.mask, orc.mask)
+    gen = torch.Generator().manual_seed(acc * 100 + acs)
+    x = torch.randn(2, 12, 2, 192, 192, generator=gen)
+    y = orc(torch.randn(2, 12, 2, 192, 192, generator=gen)) \
+        + 0.1 * torch.randn(2, 12, 2, 192, 192, generator=gen)
+    assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    assert_close(op.loss(x.to(dev), y.to(dev)), orc.loss(x, y), RTOL, "per-chain loss")
+
+
+def test_autograd_routes(dev):
+    """loss() and op(x) inside an autograd graph (LatentWrapper / custom callers) agree with the
+    fused gradient() and with the oracle's autograd."""
+    op, orc = make_op("same_mask"), MRIOracle(6, "same_mask", 192, 12, 24)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 12, 2, 192, 192, generator=gen)
+    y = torch.randn(1, 12, 2, 192, 192, generator=gen)       # batch-1 measurement broadcasts
+    w = torch.tensor([0.5, -2.0])
+    xr = x.clone().requires_grad_(True)
+    (orc.loss(xr, y) * w).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    (op.loss(xd, y.to(dev)) * w.to(dev)).sum().backward()
+    assert_close(xd.grad, xr.grad, RTOL, "weighted loss backward")
+    # through op(x): generic autograd of sum((A x - y)^2) like base.py:40-41
+    xd2 = x.to(dev).requires_grad_(True)
+    ((op(xd2) - y.to(dev)) ** 2).flatten(1).sum(-1).sum().backward()
+    g_fused = op.gradient(x.to(dev), y.to(dev))
+    assert_close(xd2.grad, g_fused, RTOL, "autograd through op(x)")
+    # adjoint identity <A x, g> = <x, A^H g>
+    gk = torch.randn(2, 12, 2, 192, 192, generator=gen).to(dev)
+    lhs = (op(x.to(dev)) * gk).sum().double()
+    rhs = (x.to(dev) * op._launch_adjoint(gk)).sum().double()
+    assert abs(lhs - rhs) / abs(lhs) <= 1e-4
+
+
+def test_config_batch_properties(dev):
+    """BASELINE config size (B = 32): chains are independent and the forward is linear."""
+    op = make_op("same_mask")
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x1 = torch.randn(32, 12, 2, 192, 192, device=dev, generator=gen)
+    x2 = torch.randn(32, 12, 2, 192, 192, device=dev, generator=gen)
+    y = op(x2[:1])
+    assert_close(op(1.5 * x1 - x2), 1.5 * op(x1) - op(x2), RTOL, "linearity")
+    g, _ = op.gradient(x1, y, return_loss=True)
+    g5 = op.gradient(x1[5:6], y)
+    assert torch.equal(g[5:6], g5)
+    # zero residual at the truth: loss 0, gradient 0
+    g0, l0 = op.gradient(x2[:1], y, return_loss=True)
+    assert l0.item() <= 1e-6 * (y ** 2).sum().item()
+    assert g0.abs().max().item() <= 1e-3 * g.abs().max().item()
+
+
+def test_rejects_other_resolutions(dev):
+    from step_amd.forward_operator import get_operator
+    op = get_operator("mri", acc_factor=4, mode="same_mask", resolution=64, frames=5, num_acs_lines=8)
+    with pytest.raises(RuntimeError, match="only resolution 192"):
+        op(torch.randn(1, 5, 2, 64, 64, device=dev))
