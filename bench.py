@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the DAPS measurement-consistency hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--task blackhole|mri] [--batch B]
+
+A "step" is one pass of the hot path over one batch of synthetic chains: for every chain one
+Langevin data step = operator loss forward + adjoint (``operator.gradient(x, y, return_loss=True)``,
+reference sampler/daps.py:100) at the shapes of configs/task/*.yaml.  The default workload is
+BASELINE.json configs[1]: the black-hole operator, 64 x 1 x 256 x 256 video, 8 stations (F = 28,
+K_cp = 1344, K_ca = 1280), B = 64 chains per GPU (config 4's num_samples), separable MFMA path.
+Inputs are resident in HBM before the timed region.  value = chain-steps / s over all GPUs.
+
+Multi-GPU: chains are independent, so each rank runs its own B chains (weak scaling) with no
+data-path collective; the barrier + MAX-over-ranks timing is the only communication.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md, HBM3E spec peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--task", default="blackhole", choices=["blackhole", "mri"])
+    p.add_argument("--batch", type=int, default=None, help="chains per GPU (64 blackhole, 32 mri)")
+    p.add_argument("--path", default="sep", choices=["sep", "dense"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-reps", type=int, default=8)
+    return p.parse_args()
+
+
+def event_ms(pairs):
+    return [a.elapsed_time(b) for a, b in pairs]
+
+
+def build_blackhole(dev, path):
+    from step_amd import eht_lite
+    from step_amd.forward_operator import BlackHoleImagingTorch
+    tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
+    op = BlackHoleImagingTorch(imsize=256, w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.26,
+                               loss_normalize=True, num_frames=64, ref_multiplier=0.001, device=dev,
+                               obs_table=tab, force_dense=(path == "dense"))
+    return op, tab
+
+
+def cpu_baseline_blackhole(tab, reps):
+    """The oracle = the reference's formulation (broadcast-multiply DFT evaluated twice per loss,
+    generic autograd) on the host cores, B = 1 chain, `reps` gradient calls."""
+    from oracle import eht_synth
+    from oracle.bh_oracle import BlackholeOracle, closure_tables
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    A = np.stack([eht_synth.ftmatrix_dense(eht_synth.PSIZE, 256, 256, tab["uv"][i]) for i in range(64)])
+    A = torch.from_numpy(A).to(torch.complex64).unsqueeze(0)
+    cpi, cpc, cai, cac = closure_tables(tab["times"], tab["t1"], tab["t2"], tab["tri"], tab["quad"])
+    sigma = torch.from_numpy(tab["sigma"]).float() / 0.001
+    orc = BlackholeOracle(A, sigma, torch.tensor(cpi), torch.tensor(cpc), torch.tensor(cai),
+                          torch.tensor(cac), 64, 256, 256, w_vis=0, w_amp=0, w_cphase=1,
+                          w_logcamp=1, w_flux=0.26, loss_normalize=True)
+    g = torch.Generator().manual_seed(37)
+    x = torch.rand(1, 64, 1, 256, 256, generator=g) * 2 - 1
+    y = orc(torch.rand(1, 64, 1, 256, 256, generator=g) * 2 - 1)
+    orc.gradient(x, y, return_loss=True)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.gradient(x, y, return_loss=True)
+    dt = time.perf_counter() - t0
+    return dict(value=reps / dt, unit="chain-steps/s", cores=threads, kind="port",
+                sample="%d x oracle gradient (loss fwd + autograd bwd, reference formulation), "
+                       "B=1, 64x1x256x256, F=28" % reps)
+
+
+def cpu_baseline_mri(reps):
+    from oracle.mri_oracle import MRIOracle
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    orc = MRIOracle(6, "same_mask", 192, 12, 24)
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(8, 12, 2, 192, 192, generator=g)
+    y = orc(torch.randn(1, 12, 2, 192, 192, generator=g))
+    orc.gradient(x, y, return_loss=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.gradient(x, y, return_loss=True)
+    dt = time.perf_counter() - t0
+    return dict(value=8 * reps / dt, unit="chain-steps/s", cores=threads, kind="port",
+                sample="%d x oracle gradient, B=8, 12x2x192x192, acc 6 / 24 ACS" % reps)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch or (64 if a.task == "blackhole" else 32)
+    gen = torch.Generator(device=dev).manual_seed(37 + rank)
+
+    if a.task == "blackhole":
+        op, tab = build_blackhole(dev, a.path)
+        x = torch.rand(B, 64, 1, 256, 256, device=dev, generator=gen) * 2 - 1
+        y = op(torch.rand(1, 64, 1, 256, 256, device=dev, generator=gen) * 2 - 1)
+        workload = "blackhole operator loss fwd + adjoint, 64x1x256x256, 8 stations F=28 K_cp=1344 K_ca=1280"
+    else:
+        from step_amd.forward_operator import get_operator
+        op = get_operator("mri", acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+        x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
+        y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
+        workload = "mri operator loss fwd + adjoint, 12x2x192x192, acc 6 / 24 ACS same_mask"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    barrier()
+    op._prof = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        grad, loss = op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, op._prof = op._prof, None
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    assert torch.isfinite(loss).item()
+
+    if rank == 0:
+        kern = {k: float(np.mean(event_ms(v))) for k, v in prof.items()}
+        if a.task == "blackhole":
+            T, F, HW = 64, 28, 256 * 256
+            flop = 4.0 * T * F * HW * B                       # per direction per launch
+            per = {k: dict(ms=kern[k], tflops=flop / (kern[k] * 1e-3) / 1e12) for k in ("dft_fwd", "dft_adj")}
+            dom = max(per, key=lambda k: per[k]["ms"])
+            roof = dict(bound="mfma", kernel=dom + "_" + op.path, achieved=per[dom]["tflops"],
+                        peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
+                        algorithmic="4*T*F*H*W flop per chain per direction x %d chains" % B,
+                        kernels_ms=kern,
+                        other={k: v["tflops"] for k, v in per.items() if k != dom})
+        else:
+            byts = 24.0 * 12 * 192 * 192 * B                  # read x, read y, write grad
+            gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        algorithmic="24*T*R*R bytes per chain x %d chains" % B, kernels_ms=kern)
+        out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
+                   unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=1e3 * dt / a.steps, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
+                               parallelism="independent chains, %d per GPU" % B),
+                   roofline=roof)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline_blackhole(tab, a.cpu_reps) if a.task == "blackhole"
+                                   else cpu_baseline_mri(a.cpu_reps * 4))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,12 @@ with the library's own message."""
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the library is opened: libstep_amd.so needs libamdhip64.so.7 and
+# has to bind to the HIP runtime torch bundles (same soname), so that both share one runtime,
+# one device context and torch's streams.  Loaded the other way round the process ends up with
+# ROCm's system runtime underneath torch and no device is visible.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstep_amd.so")
 

@@ -274,6 +274,19 @@ class BlackHoleImagingTorch(Operator):
         return self._A_vis
 
     # ------------------------------------------------------------------ kernel launches
+    _prof = None      # bench.py sets this to {} to collect (start, end) event pairs per kernel
+
+    def _tick(self):
+        if self._prof is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def _tock(self, name, start):
+        if start is not None:
+            self._prof.setdefault(name, []).append((start, self._tick()))
+
     def _video(self, x):
         x = x.detach().to(device=self.device, dtype=torch.float32)
         return x.reshape(-1, self.T, self.H * self.W).contiguous()
@@ -285,6 +298,7 @@ class BlackHoleImagingTorch(Operator):
         vis = torch.empty(B, self.T * self.F, 2, device=self.device, dtype=torch.float32)
         flux = torch.empty(B, self.T, device=self.device, dtype=torch.float32)
         L, st = _lib.lib(), _lib.stream_of(xv)
+        t0 = self._tick()
         if self.path == "sep":
             rc = L.bh_dft_fwd_sep(self._ey_t.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
                                   self.H, self.W, xv.data_ptr(), B, scale, shift, clip_min,
@@ -296,6 +310,7 @@ class BlackHoleImagingTorch(Operator):
             rc = L.bh_dft_fwd_dense(self._a_frag.data_ptr(), self.T, self.F, HW, xv.data_ptr(), B,
                                     scale, shift, clip_min, vis.data_ptr(), flux.data_ptr(),
                                     ws.data_ptr(), st)
+        self._tock("dft_fwd", t0)
         _lib.check(rc, "bh_dft_fwd_" + self.path)
         return torch.view_as_complex(vis), flux
 
@@ -305,6 +320,7 @@ class BlackHoleImagingTorch(Operator):
         grad = torch.empty(B, self.T, self.H * self.W, device=self.device, dtype=torch.float32)
         L, st = _lib.lib(), _lib.stream_of(grad)
         cs = None if chain_scale is None else chain_scale.data_ptr()
+        t0 = self._tick()
         if self.path == "sep":
             rc = L.bh_dft_adj_sep(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
                                   self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
@@ -313,6 +329,7 @@ class BlackHoleImagingTorch(Operator):
             rc = L.bh_dft_adj_dense(self._a_rows.data_ptr(), self.T, self.F, self.H * self.W,
                                     gvis.data_ptr(), gflux.data_ptr(), cs, B, out_scale,
                                     grad.data_ptr(), st)
+        self._tock("dft_adj", t0)
         _lib.check(rc, "bh_dft_adj_" + self.path)
         return grad
 
@@ -343,10 +360,12 @@ class BlackHoleImagingTorch(Operator):
         gvis = torch.empty(B, self.T * self.F, 2, device=dev, dtype=torch.float32) if need_grad else None
         gflux = torch.empty(B, self.T, device=dev, dtype=torch.float32) if need_grad else None
         meas, keep = self._meas(y)
+        t0 = self._tick()
         rc = _lib.lib().bh_closure_loss(vis.data_ptr(), flux.data_ptr(), B, C.byref(self._tab),
                                         C.byref(meas), C.byref(self._weights), loss.data_ptr(),
                                         chi2.data_ptr(), _lib.ptr(gvis), _lib.ptr(gflux),
                                         _lib.stream_of(vis))
+        self._tock("closure", t0)
         _lib.check(rc, "bh_closure_loss")
         self.last_chi2 = chi2        # raw (vis, amp, cphase, logcamp, flux) per chain
         return loss, gvis, gflux

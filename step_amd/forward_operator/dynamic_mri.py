@@ -76,6 +76,8 @@ class DynamicMRI(Operator):
         self._max_rows = int(nrows.max())
         self._dev_tables = {}
 
+    _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
+
     def _tables(self, device):
         key = str(device)
         if key not in self._dev_tables:
@@ -123,11 +125,19 @@ class DynamicMRI(Operator):
         part = torch.empty(B * T, device=x.device, dtype=torch.float32)
         loss = torch.empty(B, device=x.device, dtype=torch.float32)
         grad = torch.empty_like(x) if need_grad else None
+        t0 = None
+        if self._prof is not None:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(x.device))
         rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
                                       self.resolution, rows.data_ptr(), nrows.data_ptr(),
                                       self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
                                       part.data_ptr(), loss.data_ptr(), _lib.ptr(grad),
                                       _lib.stream_of(x))
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream(x.device))
+            self._prof.setdefault("mri_loss_grad", []).append((t0, t1))
         _lib.check(rc, "mri_loss_grad")
         return loss, grad
 
