@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstep_amd.so")
+LIB_PATH = os.environ.get("STEP_AMD_LIB") or os.path.join(_HERE, "libstep_amd.so")   # env: A/B builds
 
 c_f = C.c_float
 c_i = C.c_int

@@ -14,12 +14,12 @@
 //   A operand from an LDS image of ey ([y][64], conflict-free ds_read_b32), B operand straight
 //   from global memory as coalesced dwords (one 128-byte row segment per half wave), two
 //   v_mfma_f32_32x32x2_f32 per loaded dword.  Epilogue: complex multiply by ex in the
-//   accumulator layout, a 31-shuffle reduce-scatter over the 32 columns, fixed-order sum over strips.
+//   accumulator layout, column sums through an LDS transpose, fixed-order sum over strips.
 // adjoint, one workgroup (8 waves) per (chain, frame), one 32-column strip per wave:
 //   grad[y][x] = sum_k G[k][y] EXK[k][x]        M = y, N = x, K = 2F+1 rows
 //   G[k][y] (g folded into ey) is built in LDS, EXK lives in registers per strip,
 //   accumulator rows are image rows -> 128-byte row stores.
-// Two workgroups per CU (LDS 2 x 64 KB, <= 128 registers per lane): four waves per SIMD hide
+// Two workgroups per CU (LDS 2 x 66 KB, <= 128 registers per lane): four waves per SIMD hide
 // the dword loads / row stores behind the other waves' MFMAs.
 #include "common.h"
 
@@ -28,9 +28,88 @@
 #define SEP_U 8           // k-steps per software-pipeline stage of the forward (16 image rows)
 #define SEP_MAX_STRIPS 16 // W <= 512
 
+// One strip of the forward: tot0[r] = Re Z[f][x], tot1[r] = Im Z[f][x], f = mfma32_row(r, h).
+// acc0/acc1 collect one MFMA chain per pipeline stage (SEP_U k-steps = 16 image rows, started
+// from C = 0) and are then added into tot0/tot1: short fma chains keep the fp32 rounding of
+// the H-row sum at the level of torch's pairwise CPU sum.
+__device__ __forceinline__ void fwd_strip(const float* __restrict__ xf, const float* eyl, int xo,
+                                          int W, int nblk, int h, int li, float scale, float shift,
+                                          float clip_min, f32x16& tot0, f32x16& tot1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot0[r] = tot1[r] = 0.f;
+    float xa[SEP_U], xb[SEP_U];
+#define SEP_LOAD(dst, blk)                                                         \
+    _Pragma("unroll") for (int u = 0; u < SEP_U; ++u)                              \
+        dst[u] = xf[xo + (2 * ((blk) * SEP_U + u)) * W];
+#ifdef EXP_FWD_NOFLUSH
+#define SEP_FLUSH tot0 = acc0; tot1 = acc1;
+#define SEP_ACCINIT acc0 = tot0; acc1 = tot1;
+#else
+#define SEP_FLUSH _Pragma("unroll") for (int r = 0; r < 16; ++r) { tot0[r] += acc0[r]; tot1[r] += acc1[r]; }
+#define SEP_ACCINIT _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#endif
+#define SEP_COMPUTE(src, blk)                                                      \
+    {                                                                              \
+        f32x16 acc0, acc1;                                                         \
+        SEP_ACCINIT                                                                \
+        _Pragma("unroll") for (int u = 0; u < SEP_U; ++u) {                        \
+            const float xv = prep_pixel(src[u], scale, shift, clip_min);           \
+            const float* ar = eyl + (2 * ((blk) * SEP_U + u) + h) * 64 + li;       \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[0], xv, acc0, 0, 0, 0); \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32], xv, acc1, 0, 0, 0);\
+        }                                                                          \
+        SEP_FLUSH                                                                  \
+    }
+    SEP_LOAD(xa, 0);
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; blk += 2) {
+        if (blk + 1 < nblk) { SEP_LOAD(xb, blk + 1); }
+        SEP_COMPUTE(xa, blk);
+        if (blk + 2 < nblk) { SEP_LOAD(xa, blk + 2); }
+        if (blk + 1 < nblk) { SEP_COMPUTE(xb, blk + 1); }
+    }
+#undef SEP_LOAD
+#undef SEP_COMPUTE
+}
+
+// Epilogue of one strip: p[f] = sum_x ex[f][x] Z[f][x] over the strip's 32 columns.
+// Each lane multiplies its 16 rows, the wave transposes through its private LDS scratch
+// ([32 values][64 lanes]), lane (i, h) sums value i of half h over the 32 columns with a
+// rotated start (bank-conflict free) in a fixed order, and stores into sred[strip].
+__device__ __forceinline__ void fwd_reduce(const f32x16& tot0, const f32x16& tot1,
+                                           const float* __restrict__ exr,
+                                           const float* __restrict__ exi, int W, int xcol, int lane,
+                                           float* scr, float* sred_strip) {
+    const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = mfma32_row(r, h);
+        const float er = exr[f * W + xcol], ei = exi[f * W + xcol];
+        scr[r * 64 + lane] = er * tot0[r] - ei * tot1[r];
+        scr[(16 + r) * 64 + lane] = er * tot1[r] + ei * tot0[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+    const float* row = scr + li * 64 + h * 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += row[(j + li) & 31];
+    // lane (li, h): component c = li >> 4, baseline f = mfma32_row(li & 15, h)
+    sred_strip[(li >> 4) * 32 + mfma32_row(li & 15, h)] = s;
+}
+
+// floats in front of sred: the ey image, or the aliased transpose scratch if that is larger
+__host__ __device__ static inline int fwd_sred_offset(int H, int nstrip) {
+    const int ey = H * 64, scr = SEP_WAVES * 2048;
+    return (nstrip <= SEP_WAVES && ey < scr) ? scr : ey;
+}
+
 // ------------------------------------------------------------------------------- forward
 // HC / WC: compile-time image height / width (0 = runtime values, at half the occupancy): the
 // row loads then take scalar-base + immediate addressing instead of one address register each.
+// LDS: ey image [H][64] | sred [nstrip][64] | (only when W > 256) scratch [8][32][64];
+// with W <= 256 every wave owns at most one strip and the scratch aliases the ey image once
+// all waves are past their MFMA loop.
 template <int HC, int WC>
 __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
     const float* __restrict__ ey_t, const float* __restrict__ ex_ri, const float* __restrict__ x,
@@ -38,8 +117,9 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
     float shift, float clip_min) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = HC ? HC : Hrt, W = WC ? WC : Wrt;
+    const int nstrip = W >> 5, nblk = (H / 2) / SEP_U;
     float* eyl = lds;                         // [H][64]
-    float* sred = lds + (size_t)H * 64;       // [nstrip][64]
+    float* sred = lds + fwd_sred_offset(H, nstrip);   // [nstrip][64]
     const int b = blockIdx.x, t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -54,70 +134,26 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
     const float* xf = x + ((size_t)b * T + t) * H * W;
     const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W;
     const float* exi = ex_ri + ((size_t)t * 2 + 1) * 32 * W;
-    const int nstrip = W >> 5, nblk = (H / 2) / SEP_U;
 
-    for (int strip = wave; strip < nstrip; strip += SEP_WAVES) {
-        const int xcol = strip * 32 + li;
-        const int xo = h * W + xcol;                          // row 2*ks + h, per-lane int offset
-        // acc0/acc1 collect one MFMA chain per pipeline stage (SEP_U k-steps = 16 image rows,
-        // started from C = 0) and are then added into tot0/tot1: short fma chains keep the fp32
-        // rounding of the H-row sum at the level of torch's pairwise CPU sum.
+    if (nstrip <= SEP_WAVES) {
         f32x16 tot0, tot1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tot0[r] = tot1[r] = 0.f;
-
-        float xa[SEP_U], xb[SEP_U];
-#define SEP_LOAD(dst, blk)                                                         \
-    _Pragma("unroll") for (int u = 0; u < SEP_U; ++u)                              \
-        dst[u] = xf[xo + (2 * ((blk) * SEP_U + u)) * W];
-#define SEP_COMPUTE(src, blk)                                                      \
-    {                                                                              \
-        f32x16 acc0, acc1;                                                         \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;    \
-        _Pragma("unroll") for (int u = 0; u < SEP_U; ++u) {                        \
-            const float xv = prep_pixel(src[u], scale, shift, clip_min);           \
-            const float* ar = eyl + (2 * ((blk) * SEP_U + u) + h) * 64 + li;       \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[0], xv, acc0, 0, 0, 0); \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32], xv, acc1, 0, 0, 0);\
-        }                                                                          \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                           \
-            tot0[r] += acc0[r];                                                    \
-            tot1[r] += acc1[r];                                                    \
-        }                                                                          \
-    }
-        SEP_LOAD(xa, 0);
-#pragma unroll 1
-        for (int blk = 0; blk < nblk; blk += 2) {
-            if (blk + 1 < nblk) { SEP_LOAD(xb, blk + 1); }
-            SEP_COMPUTE(xa, blk);
-            if (blk + 2 < nblk) { SEP_LOAD(xa, blk + 2); }
-            if (blk + 1 < nblk) { SEP_COMPUTE(xb, blk + 1); }
+        const bool mine = wave < nstrip;
+        const int xcol = wave * 32 + li;
+        if (mine) fwd_strip(xf, eyl, h * W + xcol, W, nblk, h, li, scale, shift, clip_min, tot0, tot1);
+        __syncthreads();                      // every wave is done reading the ey image
+#ifndef EXP_FWD_NOEPI
+        if (mine) fwd_reduce(tot0, tot1, exr, exi, W, xcol, lane, lds + wave * 2048, sred + wave * 64);
+#else
+        if (mine) sred[wave * 64 + lane] = tot0[0] + tot1[0] + tot0[5] + tot1[9];
+#endif
+    } else {
+        float* scr = sred + nstrip * 64 + wave * 2048;
+        for (int strip = wave; strip < nstrip; strip += SEP_WAVES) {
+            f32x16 tot0, tot1;
+            const int xcol = strip * 32 + li;
+            fwd_strip(xf, eyl, h * W + xcol, W, nblk, h, li, scale, shift, clip_min, tot0, tot1);
+            fwd_reduce(tot0, tot1, exr, exi, W, xcol, lane, scr, sred + strip * 64);
         }
-#undef SEP_LOAD
-#undef SEP_COMPUTE
-        // tot0[r] = Re Z[f][x], tot1[r] = Im Z[f][x] with f = mfma32_row(r, h), x = xcol;
-        // v[r] / v[16+r] = Re / Im of ex[f][x] * Z[f][x]
-        float v[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = mfma32_row(r, h);
-            const float er = exr[f * W + xcol], ei = exi[f * W + xcol];
-            v[r] = er * tot0[r] - ei * tot1[r];
-            v[16 + r] = er * tot1[r] + ei * tot0[r];
-        }
-        // reduce-scatter over the 32 columns of each half wave: lane li ends with the total of v[li]
-#pragma unroll
-        for (int m = 16, n = 32; m >= 1; m >>= 1, n >>= 1) {
-            const bool up = (li & m) != 0;
-#pragma unroll
-            for (int i = 0; i < n / 2; ++i) {
-                const float keep = up ? v[i + n / 2] : v[i];
-                const float send = up ? v[i] : v[i + n / 2];
-                v[i] = keep + __shfl_xor(send, m);
-            }
-        }
-        // lane li of half h: component c = li >> 4, baseline f = mfma32_row(li & 15, h)
-        sred[strip * 64 + (li >> 4) * 32 + mfma32_row(li & 15, h)] = v[0];
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -137,7 +173,11 @@ extern "C" int bh_dft_fwd_sep(const float* ey_t, const float* ex_ri, int T, int 
     STEP_REQUIRE(H > 0 && H % 32 == 0 && H <= 512, "bh_dft_fwd_sep: need H %% 32 == 0, H <= 512 (H=%d)", H);
     STEP_REQUIRE(W > 0 && W % 32 == 0 && W <= 32 * SEP_MAX_STRIPS, "bh_dft_fwd_sep: need W %% 32 == 0, W <= 512 (W=%d)", W);
     STEP_REQUIRE(T <= 65535, "bh_dft_fwd_sep: T too large");
-    const size_t lds = ((size_t)H * 64 + (W / 32) * 64) * sizeof(float);
+    const int nstrip = W / 32;
+    size_t floats = (size_t)fwd_sred_offset(H, nstrip) + nstrip * 64;
+    if (nstrip > SEP_WAVES) floats += SEP_WAVES * 2048;          // separate transpose scratch
+    const size_t lds = floats * sizeof(float);
+    STEP_REQUIRE(lds <= 160 * 1024, "bh_dft_fwd_sep: %zu B of LDS needed (H=%d W=%d)", lds, H, W);
     if (H == 256 && W == 256) {
         step_allow_lds((const void*)k_dft_fwd_sep<256, 256>, lds);
         hipLaunchKernelGGL((k_dft_fwd_sep<256, 256>), dim3(B, T), dim3(SEP_THREADS), lds,
@@ -156,73 +196,86 @@ extern "C" int bh_dft_fwd_sep(const float* ey_t, const float* ex_ri, int T, int 
 // ------------------------------------------------------------------------------- adjoint
 // HC / WC: compile-time image height / width (0 = use the runtime values) so that the LDS reads
 // of G and the row stores take immediate offsets instead of one address register each.
-template <int HC, int WC>
-__global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_adj_sep(
+template <int HC, int WC, int YS>
+__global__ __launch_bounds__(SEP_THREADS, (HC ? 8 : 2)) void k_dft_adj_sep(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
     const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, int Hrt, int Wrt,
     float out_scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = HC ? HC : Hrt, W = WC ? WC : Wrt;
+    const int Hs = H / YS, y0 = blockIdx.z * Hs;   // this workgroup's image rows [y0, y0 + Hs)
     const int KP = (2 * F + 2) & ~1;          // k rows: Re f | Im f | flux | (zero pad)
-    float* G = lds;                           // [KP][H]
-    float* g2 = lds + (size_t)KP * H;         // [2F + 1]
+    float* G = lds;                           // [KP][Hs]
+    float* g2 = lds + KP * Hs;                // [2F + 2]: Re g | Im g | gflux | 0
     const int b = blockIdx.x, t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
 
-    for (int e = threadIdx.x; e < 2 * F + 1; e += SEP_THREADS) {
-        float v;
+    for (int e = threadIdx.x; e < 2 * F + 2; e += SEP_THREADS) {
+        float v = 0.f;
         if (e < F) v = gvis[(((size_t)b * T + t) * F + e) * 2];
         else if (e < 2 * F) v = gvis[(((size_t)b * T + t) * F + (e - F)) * 2 + 1];
-        else v = gflux[(size_t)b * T + t];
+        else if (e == 2 * F) v = gflux[(size_t)b * T + t];
         g2[e] = cs * v;
     }
     __syncthreads();
-    const float* eyr = ey_ri + ((size_t)t * 2 + 0) * 32 * H;
-    const float* eyi = ey_ri + ((size_t)t * 2 + 1) * 32 * H;
-    for (int e = threadIdx.x; e < KP * H; e += SEP_THREADS) {
-        const int k = e / H, y = e - k * H;
-        float v = 0.f;
-        if (k < F) v = eyr[k * H + y] * g2[k] + eyi[k * H + y] * g2[F + k];
-        else if (k < 2 * F) {
-            const int f = k - F;
-            v = eyr[f * H + y] * g2[F + f] - eyi[f * H + y] * g2[f];
-        } else if (k == 2 * F) v = g2[2 * F];
+    // G[k][y]: k < F: Re(conj(ey) g) = eyR gR + eyI gI;  F <= k < 2F: Im = eyR gI - eyI gR;
+    // k = 2F: gflux (ey = 1);  branch-free so that the table loads of all iterations overlap
+    const float* eyr = ey_ri + ((size_t)t * 2 + 0) * 32 * H + y0;
+    const float* eyi = ey_ri + ((size_t)t * 2 + 1) * 32 * H + y0;
+#ifndef EXP_ADJ_NOG
+#pragma unroll 4
+    for (int e = threadIdx.x; e < KP * Hs; e += SEP_THREADS) {
+        const int k = e / Hs, y = e - k * Hs;
+        const bool im = k >= F;
+        const int f = min(im ? k - F : k, F);               // f = F: the flux row (ey = 1 + 0i)
+        const float a = eyr[f * H + y], c = eyi[f * H + y];
+        const float gr = g2[min(f, F - 1)], gi = g2[F + min(f, F - 1)];
+        float v = im ? a * gi - c * gr : a * gr + c * gi;
+        if (k >= 2 * F) v = (k == 2 * F) ? g2[2 * F] : 0.f;
         G[e] = v;
     }
+#endif
     __syncthreads();
 
     const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W;
     const float* exi = ex_ri + ((size_t)t * 2 + 1) * 32 * W;
-    float* gf = grad + ((size_t)b * T + t) * H * W;
-    const int ksteps = KP >> 1, nstrip = W >> 5, ntile = H >> 5;
+    float* gf = grad + ((size_t)b * T + t) * H * W + (size_t)y0 * W;
+    const int ksteps = KP >> 1, nstrip = W >> 5, ntile = Hs >> 5;
     for (int strip = wave; strip < nstrip; strip += SEP_WAVES) {
         const int xcol = strip * 32 + li;
         float bx[32];
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < 32; ++s) {                      // EXK[k][x]: Re ex | Im ex | 1 | 0
             const int k = 2 * s + h;
-            float v = 0.f;
-            if (k < F) v = exr[k * W + xcol];
-            else if (k < 2 * F) v = exi[(k - F) * W + xcol];
-            else if (k == 2 * F) v = 1.f;
-            bx[s] = v;
+            const bool im = k >= F;
+            const int f = min(im ? k - F : k, F);           // row F of ex_ri is 1 + 0i
+            const float* tab = (im && k < 2 * F) ? exi : exr;
+            const float v = tab[f * W + xcol];
+            bx[s] = (k <= 2 * F) ? v : 0.f;
         }
 #pragma unroll 1
         for (int tile = 0; tile < ntile; ++tile) {
-            const float* gp = G + h * H + tile * 32 + li;
+            const float* gp = G + h * Hs + tile * 32 + li;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#ifndef EXP_ADJ_NOMFMA
 #pragma unroll
             for (int s = 0; s < 32; ++s)
                 if (s < ksteps)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[(2 * s) * H], bx[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[(2 * s) * Hs], bx[s], acc, 0, 0, 0);
+#else
+            acc[0] = gp[0] * bx[0];
+#endif
             const int go = (tile * 32 + 4 * h) * W + xcol;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
+#ifdef EXP_ADJ_NOSTORE
+                if (acc[r] == 1234567.f)
+#endif
                 gf[go + ((r & 3) + 8 * (r >> 2)) * W] = acc[r];
         }
     }
@@ -237,15 +290,18 @@ extern "C" int bh_dft_adj_sep(const float* ey_ri, const float* ex_ri, int T, int
     STEP_REQUIRE(W > 0 && W % 32 == 0 && W <= 32 * SEP_MAX_STRIPS, "bh_dft_adj_sep: need W %% 32 == 0, W <= 512 (W=%d)", W);
     STEP_REQUIRE(T <= 65535, "bh_dft_adj_sep: T too large");
     const int KP = (2 * F + 2) & ~1;
-    const size_t lds = ((size_t)KP * H + 2 * F + 1) * sizeof(float);
     if (H == 256 && W == 256) {
-        step_allow_lds((const void*)k_dft_adj_sep<256, 256>, lds);
-        hipLaunchKernelGGL((k_dft_adj_sep<256, 256>), dim3(B, T), dim3(SEP_THREADS), lds,
+        // two workgroups per frame (128 image rows each): 30 KB of LDS and 56 registers per lane
+        // let four workgroups share a CU, which keeps the matrix pipe fed while others build G
+        const size_t lds = ((size_t)KP * 128 + 2 * F + 2) * sizeof(float);
+        step_allow_lds((const void*)k_dft_adj_sep<256, 256, 2>, lds);
+        hipLaunchKernelGGL((k_dft_adj_sep<256, 256, 2>), dim3(B, T, 2), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_ri, ex_ri, gvis_c64, gflux, chain_scale, grad, T,
                            F, H, W, out_scale);
     } else {
-        step_allow_lds((const void*)k_dft_adj_sep<0, 0>, lds);
-        hipLaunchKernelGGL((k_dft_adj_sep<0, 0>), dim3(B, T), dim3(SEP_THREADS), lds,
+        const size_t lds = ((size_t)KP * H + 2 * F + 2) * sizeof(float);
+        step_allow_lds((const void*)k_dft_adj_sep<0, 0, 1>, lds);
+        hipLaunchKernelGGL((k_dft_adj_sep<0, 0, 1>), dim3(B, T), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_ri, ex_ri, gvis_c64, gflux, chain_scale, grad, T,
                            F, H, W, out_scale);
     }

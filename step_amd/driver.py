@@ -1,0 +1,100 @@
+"""Chain-sharded posterior sampling driver: the multi-GPU counterpart of the reference's
+sequential loop (reference sample.py:56-76: per test video, ``num_samples`` chains one after
+another at batch size 1 on one GPU).
+
+Posterior chains are independent, so the path shards with no data-path collective:
+work items (video index, sample index) are dealt round-robin to ranks, each rank batches its
+chains of one video into ONE ``sampler.sample`` call (the operator kernels and LatentDAPS are
+batch-agnostic; the measurement broadcasts from batch 1), and the only communication is a
+gather of the finished samples to rank 0 (RCCL over xGMI when the backend is nccl; gloo on
+CPU in the tests).  Per-chain seeds are ``seed + global chain id``: the reference draws all
+chains from one global stream (sample.py:28), which no sharded run can reproduce, so
+chain-level parity with the reference is statistical while operator-level parity is exact.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["init_distributed", "shard_items", "chain_generator", "gather_to_rank0",
+           "sample_posterior"]
+
+
+def init_distributed(backend=None):
+    """One process per GPU (torchrun env).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    cuda = torch.cuda.is_available()
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend or ("nccl" if cuda else "gloo"))
+    if cuda:
+        torch.cuda.set_device(local)
+        return rank, world, torch.device("cuda", local)
+    return rank, world, torch.device("cpu")
+
+
+def shard_items(n_items, rank, world):
+    """Item ids of this rank: r, r + P, r + 2P, ...  (SURVEY section 8e)."""
+    return list(range(rank, n_items, world))
+
+
+def chain_generator(seed, chain_id, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) + int(chain_id))
+    return g
+
+
+def gather_to_rank0(local, ids, n_items, group=None):
+    """local: [n_local, ...] tensor of this rank's results for item ids `ids`.
+    Returns on rank 0 a tensor [n_items, ...] in item order, None elsewhere.  Ranks may hold
+    different counts (n_items need not divide the world size): every rank pads to the maximum."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        out[torch.as_tensor(ids, dtype=torch.long, device=local.device)] = local
+        return out
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_max = (n_items + world - 1) // world
+    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        rid = shard_items(n_items, r, world)
+        out[torch.as_tensor(rid, dtype=torch.long, device=local.device)] = bufs[r][: len(rid)]
+    return out
+
+
+def sample_posterior(sampler, model, operator, measurement, num_samples, seed=37, device=None,
+                     max_batch=None, evaluator=None, gt=None, group=None):
+    """Draw `num_samples` posterior samples for ONE measurement, chains sharded over ranks and
+    batched per rank.  Returns [num_samples, *video_shape] on rank 0 (None on other ranks).
+
+    sampler: LatentDAPS-like (get_start / sample); model: prior with get_latent_shape()."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    device = device or next(model.parameters()).device
+    ids = shard_items(num_samples, rank, world)
+    outs = []
+    step = max_batch or max(len(ids), 1)
+    for i in range(0, len(ids), step):
+        chunk = ids[i: i + step]
+        # per-chain start noise from per-chain generators; the in-loop noise of a batched call
+        # comes from the rank's default generator, seeded by the first chain of the chunk
+        z = torch.stack([torch.randn(*model.get_latent_shape(), device=device,
+                                     generator=chain_generator(seed, c, device)) for c in chunk])
+        if device.type == "cuda":
+            torch.cuda.manual_seed(int(seed) + 100003 * (chunk[0] + 1))
+        else:
+            torch.manual_seed(int(seed) + 100003 * (chunk[0] + 1))
+        z_start = z * sampler.annealing_scheduler.sigma_max
+        kw = dict(gt=gt) if gt is not None else {}
+        outs.append(sampler.sample(model, z_start, operator, measurement, evaluator=evaluator, **kw))
+    if outs:
+        local = torch.cat(outs, dim=0)
+    else:                      # more ranks than chains: this rank contributes an empty shard
+        local = torch.empty((0,) + tuple(model.get_data_shape()), device=device)
+    return gather_to_rank0(local, ids, num_samples, group)

@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads and exports every symbol include/step_amd.h declares; the host
+(no-GPU) entry points validate their arguments; the Python binding lists the same symbols."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "step_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|size_t)\s+(\w+)\s*\(", src, flags=re.M)
+    assert len(names) >= 20
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from step_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(L, name), "libstep_amd.so does not export %s" % name
+
+
+def test_binding_covers_header_exactly():
+    from step_amd import _lib
+    assert set(_lib.SIGNATURES) == set(header_functions())
+    assert _lib.lib().step_abi_version() == 1
+
+
+def test_host_entry_points_reject_bad_arguments():
+    from step_amd import _lib
+    L = _lib.lib()
+    m = np.zeros((1, 16), np.float32)
+    assert L.mri_build_mask(4, 7, 16, 1, 2, _lib.ptr(m)) != 0
+    assert b"Unknown mode" in L.step_last_error()
+    assert L.mri_build_mask(0, 0, 16, 1, 2, _lib.ptr(m)) != 0
+    with pytest.raises(RuntimeError, match="rc=-1"):
+        _lib.check(L.mri_build_mask(4, 0, 16, 1, 2, None), "mri_build_mask")
+    # a triangle that needs a baseline the table does not hold -> error (reference: KeyError)
+    rt = np.array([1.0, 1.0]); a = np.array([0, 0], np.int32); b = np.array([1, 2], np.int32)
+    tt = np.array([1.0]); ts = np.array([[0, 1, 2]], np.int32)
+    out = [np.zeros((1, 3), np.int64) for _ in range(2)]
+    rc = L.bh_build_closure_tables(_lib.ptr(rt), _lib.ptr(a), _lib.ptr(b), 2, _lib.ptr(tt), _lib.ptr(ts), 1,
+                                   None, None, 0, _lib.ptr(out[0]), _lib.ptr(out[1]), None, None)
+    assert rc != 0 and b"no baseline" in L.step_last_error()
+    # GPU entry points validate shapes before touching the device
+    assert L.bh_dft_fwd_sep(None, None, 64, 28, 256, 256, None, 1, 1.0, 0.0, 0.0, None, None, None) != 0
+    assert L.mri_forward(None, 1, 12, 192, None, None, 1, 52, None, None) != 0
+    assert L.bh_dense_rows_padded(28) == 64 and L.bh_dense_rows_padded(6) == 32
+    assert L.bh_dense_packed_floats(64, 28, 65536) == 64 * 64 * 65536
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from step_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libstep_amd.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,111 @@
+"""CPU: the oracle restatement reproduces the golden fixtures (= outputs of the reference's own
+code, oracle/gen_golden.py).  This is what pins the oracle; the GPU tests then use the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.bh_oracle import Obs, closure_tables
+from oracle.mcmc_oracle import LatentWrapOracle, MCMCOracle, edm_sigmas, lr_at
+from oracle.mri_oracle import MRIOracle
+from tests.helpers import obs_from_golden, oracle_from_golden, t
+from tests.toy_model import ToyModel
+
+TIGHT = 2e-6      # same formulas, same dtype: only BLAS/vectorisation differences between CPUs
+
+
+def close(a, b, tol=TIGHT):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    if torch.is_complex(a):
+        a, b = torch.view_as_real(a), torch.view_as_real(b)
+    assert ((a - b).abs().max() <= tol * b.abs().max().clamp_min(1e-30)), \
+        ((a - b).abs().max().item(), b.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["bh_small", "bh_allterms", "bh_allterms_norm"])
+def test_blackhole_oracle_matches_reference_outputs(name, golden):
+    g = golden(name)
+    orc = oracle_from_golden(g)
+    y = obs_from_golden(g, "y_")
+    for tag, key in (("x", "x"), ("near", "x_near")):
+        x = t(g[key])
+        for f, got in zip(Obs._fields, orc(x)):
+            close(got, g["%s_obs_%s" % (tag, f)])
+        close(orc.loss(x, y), g[tag + "_loss"], 1e-5)
+        grad, lsum = orc.gradient(x, y, return_loss=True)
+        close(grad, g[tag + "_grad"], 1e-5)
+        close(lsum, g[tag + "_loss_sum"], 1e-5)
+        ev = orc.evaluate_chisq(x, y, normalize=False)
+        for k in ev:
+            close(ev[k], g["%s_eval_%s" % (tag, k)], 1e-5)
+    model = ToyModel((64, 1, int(g["imsize"]) // 2, int(g["imsize"]) // 2), 2, float(g["toy_gain"]))
+    zg, zl = LatentWrapOracle(orc, model).gradient(t(g["z"]), y, return_loss=True)
+    close(zl, g["z_loss_sum"], 1e-5)
+    assert (zg - t(g["z_grad"])).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["bh_small", "bh_allterms", "bh_allterms_norm", "bh_full_n8"])
+def test_closure_index_mapping_is_bit_exact(name, golden):
+    g = golden(name)
+    tri = [(tm,) + tuple(s) for tm, s in zip(np.repeat(np.unique(g["row_time"]), len(g["tri_sites"]) // 64), g["tri_sites"])]
+    quad = [(tm,) + tuple(s) for tm, s in zip(np.repeat(np.unique(g["row_time"]), len(g["quad_sites"]) // 64), g["quad_sites"])]
+    cpi, cpc, cai, cac = closure_tables(g["row_time"], list(g["row_t1"]), list(g["row_t2"]), tri, quad)
+    assert np.array_equal(np.array(cpi), g["cp_index"]) and np.array_equal(np.array(cpc), g["cp_conjugate"])
+    assert np.array_equal(np.array(cai), g["camp_index"]) and np.array_equal(np.array(cac), g["camp_conjugate"])
+    assert g["cp_conjugate"].sum() > 0          # the conjugated-leg branch is exercised
+
+
+@pytest.mark.parametrize("mode", ["same_mask", "split_mask", "random_split_mask"])
+def test_mri_oracle_matches_reference_outputs(mode, golden):
+    g = golden("mri_" + mode)
+    orc = MRIOracle(6, mode, 192, 12, 24, sigma=float(g["noise"]))
+    assert np.array_equal(orc.mask[0, :, 0, :, 0].numpy().astype(np.uint8), g["mask"])
+    rng = np.random.RandomState(int(g["seed"]))
+    shape = (int(g["B"]), 12, 2, 192, 192)
+    x_gt, x, nz = (torch.from_numpy(rng.randn(*shape).astype(np.float32)) for _ in range(3))
+    y = orc(x_gt) + float(g["noise"]) * nz
+    fwd = orc(x)
+    close(fwd.flatten()[::11], g["fwd_sub"], 1e-5)
+    close(fwd[0, 0], g["fwd_frame0"], 1e-5)
+    grad, lsum = orc.gradient(x, y, return_loss=True)
+    close(grad.flatten()[::11], g["grad_sub"], 1e-5)
+    close(lsum, g["loss_sum"], 1e-5)
+    close(orc.loss(x, y), g["loss"], 1e-5)
+
+
+def test_mri_masks_all_configs(golden):
+    from oracle.mri_oracle import build_mask
+    d = golden("mri_masks")
+    for key, want in d.items():
+        mode, a, c, r, f = key.rsplit("_", 4)
+        m = build_mask(int(a[1:]), mode, int(r[1:]), int(f[1:]), int(c[1:]))
+        assert np.array_equal(m[0, :, 0, :, 0].numpy().astype(np.uint8), want), key
+
+
+def test_mcmc_oracle_matches_reference_trajectories(golden):
+    from tests.test_gpu_mcmc import CASES, Replay
+    g, m = golden("bh_small"), golden("mcmc_bh_small")
+    orc, y = oracle_from_golden(g), obs_from_golden(g, "y_")
+    model = ToyModel((64, 1, 8, 8), factor=2, gain=1.5)
+    for case, (cfg, space) in CASES.items():
+        s = MCMCOracle(**cfg)
+        if space == "latent":
+            oper, start, xt = LatentWrapOracle(orc, model), t(m["z0hat"]), t(m["zt"])
+        else:
+            oper, start, xt = orc, t(m["x0hat"]), t(m[case + "_xt"])
+        with Replay(list(t(m[case + "_noise"]))):
+            out = s.sample(xt, model, start, oper, y, float(m["sigma"]), float(m["ratio"]), record=True)
+        close(out, m[case + "_result"], 1e-4)
+        close(torch.stack(s.trace), m[case + "_traj"], 1e-4)
+        assert lr_at(cfg["lr"], cfg.get("lr_min_ratio", 0.01), float(m["ratio"])) == float(m[case + "_lr"])
+    with Replay(list(t(m["mh_pixel_noise"])), list(t(m["mh_pixel_unif"]))):
+        out = MCMCOracle(num_steps=6, lr=1e-7, tau=3.0, mc_algo="MH").sample(
+            t(m["mh_pixel_xt"]), model, t(m["x0hat"]), orc, y, float(m["sigma"]), float(m["ratio"]))
+    close(out, m["mh_pixel_result"], 1e-4)
+    o = MCMCOracle(num_steps=5, lr=2e-7, tau=1.0).optimize(t(m["x0hat"]), orc, y, 0.7, 0.25)
+    close(o, m["optimize_result"], 1e-4)
+
+
+def test_edm_sigma_grid(golden):
+    e = golden("edm_sigmas")
+    assert torch.equal(edm_sigmas(25), t(e["s25"])) and torch.equal(edm_sigmas(20), t(e["s20"]))
+    assert len(e["s25"]) == 26 and e["s25"][0] == 100 and e["s25"][-1] == 0
