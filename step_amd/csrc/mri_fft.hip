@@ -27,7 +27,9 @@ struct MriLds {
     cf32* tw;      // [192]
     cf32* S;       // [192][32]
     cf32* Rk;      // [nkc][204]
-    int* rowpos;   // [192]
+    int* rowpos;   // [192]  position of k_y row in the kept-row list, -1 if masked out
+    int* rowl;     // [192]  the kept-row list (copy of the global table)
+    int* unrow;    // [192]  the masked-out rows, ascending
     float* red;    // [16]
 };
 
@@ -37,26 +39,32 @@ __device__ __forceinline__ MriLds carve(float* lds, int nkc) {
     L.S = L.tw + MRI_R;
     L.Rk = L.S + MRI_R * MRI_SW;
     L.rowpos = (int*)(L.Rk + (size_t)nkc * MRI_RS);
-    L.red = (float*)(L.rowpos + MRI_R);
+    L.rowl = L.rowpos + MRI_R;
+    L.unrow = L.rowl + MRI_R;
+    L.red = (float*)(L.unrow + MRI_R);
     return L;
 }
 static size_t mri_lds_bytes(int nkc) {
     return (size_t)(MRI_R + MRI_R * MRI_SW + (size_t)nkc * MRI_RS) * sizeof(cf32) +
-           MRI_R * sizeof(int) + 16 * sizeof(float);
+           3 * MRI_R * sizeof(int) + 16 * sizeof(float);
 }
 
 __device__ __forceinline__ float sgn(int k) { return (k & 1) ? -1.f : 1.f; }
 
-// FFT along y of the strip S[192][32] (all 32 columns), in place, natural order.
-template <int SIGN>
-__device__ __forceinline__ void strip_fft_y(const MriLds& L) {
+// Forward FFT along y of the strip S[192][32] (all 32 columns).  Pass A runs in place; pass B
+// keeps its 12 outputs in registers and writes only the kept k_y rows of the current row group,
+// sign-folded, straight into the row buffer: Rk[j][strip*32+col] = (-1)^ky X[ky][col].
+__device__ __forceinline__ void strip_fft_fwd(const MriLds& L, int strip, int g0, int nk) {
+#ifdef EXP_MRI_NOFFT
+    return;
+#endif
     const int tid = threadIdx.x, col = tid & 31;
     if (tid < 12 * 32) {
         const int bb = tid >> 5;
         cf32 v[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) v[a] = L.S[(12 * a + bb) * MRI_SW + col];
-        fft192_pass_a<SIGN>(v, bb, L.tw);
+        fft192_pass_a<-1>(v, bb, L.tw);
 #pragma unroll
         for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * MRI_SW + col] = v[c];
     }
@@ -66,17 +74,65 @@ __device__ __forceinline__ void strip_fft_y(const MriLds& L) {
         cf32 v[12];
 #pragma unroll
         for (int b = 0; b < 12; ++b) v[b] = L.S[(12 * c + b) * MRI_SW + col];
-        fft192_pass_b<SIGN>(v);
-        __syncthreads();
+        fft192_pass_b<-1>(v);
 #pragma unroll
-        for (int d = 0; d < 12; ++d) L.S[(c + 16 * d) * MRI_SW + col] = v[d];
+        for (int d = 0; d < 12; ++d) {
+            const int ky = c + 16 * d;
+            const int j = L.rowpos[ky] - g0;
+            if (j >= 0 && j < nk) {
+                const float sg = sgn(ky);
+                L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col] = c_make(sg * v[d].x, sg * v[d].y);
+            }
+        }
+    }
+    __syncthreads();                                  // S may be refilled, Rk column block complete
+}
+
+// Inverse FFT along y for one strip: pass A gathers its inputs from the kept rows of the row
+// buffer (all other k_y rows are zero), pass B stores image rows straight from registers.
+__device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0, int nk,
+                                              float* __restrict__ dr, float* __restrict__ di,
+                                              bool accumulate) {
+    const int tid = threadIdx.x, col = tid & 31;
+    if (tid < 12 * 32) {
+        const int bb = tid >> 5;
+        cf32 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const int j = L.rowpos[12 * a + bb] - g0;
+            v[a] = (j >= 0 && j < nk) ? L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col] : c_make(0.f, 0.f);
+        }
+#ifndef EXP_MRI_NOFFT
+        fft192_pass_a<1>(v, bb, L.tw);
+#endif
+#pragma unroll
+        for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * MRI_SW + col] = v[c];
     }
     __syncthreads();
+    {
+        const int c = tid >> 5;
+        cf32 v[12];
+#pragma unroll
+        for (int b = 0; b < 12; ++b) v[b] = L.S[(12 * c + b) * MRI_SW + col];
+#ifndef EXP_MRI_NOFFT
+        fft192_pass_b<1>(v);
+#endif
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+            const int g = (c + 16 * d) * MRI_R + strip * MRI_SW + col;
+            if (accumulate) { dr[g] += v[d].x; di[g] += v[d].y; }
+            else { dr[g] = v[d].x; di[g] = v[d].y; }
+        }
+    }
+    __syncthreads();                                  // S is rewritten by the next strip's pass A
 }
 
 // FFT along x of the nk kept rows Rk[nk][204], in place, natural order.
 template <int SIGN>
 __device__ __forceinline__ void rows_fft_x(const MriLds& L, int nk) {
+#ifdef EXP_MRI_NOFFT
+    return;
+#endif
     const int tid = threadIdx.x;
     for (int e = tid; e < nk * 12; e += MRI_THREADS) {
         const int j = e / 12, bb = e - 12 * j;
@@ -124,22 +180,27 @@ __device__ __forceinline__ void forward_rows(const MriLds& L, const float* __res
                                              const float* __restrict__ xi,
                                              const int* __restrict__ rowlist, int g0, int nk) {
     const int tid = threadIdx.x;
+    constexpr int NP = MRI_R * MRI_SW / MRI_THREADS;      // 12 elements of a strip per thread
+    const int col = tid & 31, row0 = tid >> 5;             // element i: row = row0 + 16 i
+    // the next strip's pixels travel to registers while the current strip is transformed
+    cf32 pre[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int g = (row0 + 16 * i) * MRI_R + col;
+        pre[i] = c_make(xr[g], xi[g]);
+    }
     for (int strip = 0; strip < MRI_R / MRI_SW; ++strip) {
-        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) {
-            const int row = e >> 5, col = e & 31;
-            const size_t g = (size_t)row * MRI_R + strip * MRI_SW + col;
-            L.S[e] = c_make(xr[g], xi[g]);
-        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) L.S[(row0 + 16 * i) * MRI_SW + col] = pre[i];
         __syncthreads();
-        strip_fft_y<-1>(L);
-        for (int e = tid; e < nk * MRI_SW; e += MRI_THREADS) {
-            const int j = e >> 5, col = e & 31;
-            const int ky = rowlist[g0 + j];
-            const cf32 v = L.S[ky * MRI_SW + col];
-            const float s = sgn(ky);
-            L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col] = c_make(s * v.x, s * v.y);
+        if (strip + 1 < MRI_R / MRI_SW) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int g = (row0 + 16 * i) * MRI_R + (strip + 1) * MRI_SW + col;
+                pre[i] = c_make(xr[g], xi[g]);
+            }
         }
-        __syncthreads();
+        strip_fft_fwd(L, strip, g0, nk);
     }
     rows_fft_x<-1>(L, nk);
 }
@@ -153,7 +214,19 @@ __device__ __forceinline__ void load_tables(const MriLds& L, const int* __restri
         L.rowpos[e] = -1;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nk_total; e += MRI_THREADS) L.rowpos[rowlist[e]] = e;
+    for (int e = threadIdx.x; e < nk_total; e += MRI_THREADS) {
+        const int r = rowlist[e];
+        L.rowpos[r] = e;
+        L.rowl[e] = r;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < MRI_R; e += MRI_THREADS) {
+        if (L.rowpos[e] < 0) {                      // rank among the masked-out rows
+            int rank = 0;
+            for (int q = 0; q < e; ++q) rank += L.rowpos[q] < 0;
+            L.unrow[rank] = e;
+        }
+    }
     __syncthreads();
 }
 
@@ -179,7 +252,7 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
         forward_rows(L, xr, xi, rowlist, g0, nk);
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
             const int j = e / MRI_R, kx = e - j * MRI_R;
-            const int ky = rowlist[g0 + j];
+            const int ky = L.rowl[g0 + j];
             const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
             const float s = sgn(kx);
             outr[(size_t)ky * MRI_R + kx] = s * v.x;
@@ -193,28 +266,9 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
 // or accumulates (later groups) the image-space result into the frame `dst` ([2][R][R]).
 __device__ __forceinline__ void adjoint_rows(const MriLds& L, const int* __restrict__ rowlist,
                                              int g0, int nk, float* __restrict__ dst) {
-    const int tid = threadIdx.x;
     rows_fft_x<1>(L, nk);
-    float* dr = dst;
-    float* di = dst + MRI_R * MRI_R;
-    for (int strip = 0; strip < MRI_R / MRI_SW; ++strip) {
-        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) L.S[e] = c_make(0.f, 0.f);
-        __syncthreads();
-        for (int e = tid; e < nk * MRI_SW; e += MRI_THREADS) {
-            const int j = e >> 5, col = e & 31;
-            L.S[rowlist[g0 + j] * MRI_SW + col] = L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col];
-        }
-        __syncthreads();
-        strip_fft_y<1>(L);
-        for (int e = tid; e < MRI_R * MRI_SW; e += MRI_THREADS) {
-            const int row = e >> 5, col = e & 31;
-            const size_t g = (size_t)row * MRI_R + strip * MRI_SW + col;
-            const cf32 v = L.S[e];
-            if (g0 == 0) { dr[g] = v.x; di[g] = v.y; }
-            else { dr[g] += v.x; di[g] += v.y; }
-        }
-        __syncthreads();
-    }
+    for (int strip = 0; strip < MRI_R / MRI_SW; ++strip)
+        strip_fft_inv(L, strip, g0, nk, dst, dst + MRI_R * MRI_R, g0 != 0);
 }
 
 // ------------------------------------------------------------------------------- loss + gradient
@@ -238,8 +292,16 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
 
     // rows outside the mask: A(x) = 0 there, the residual is -y (constant in x)
     float acc = 0.f;
-    for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS)
-        if (L.rowpos[e / MRI_R] < 0) acc += yr[e] * yr[e] + yi[e] * yi[e];
+    {
+        const int total = (MRI_R - nk_total) * MRI_R;       // branch-free so the loads batch
+#pragma unroll 8
+        for (int e = tid; e < total; e += MRI_THREADS) {
+            const int q = e / MRI_R;
+            const int g = L.unrow[q] * MRI_R + (e - q * MRI_R);
+            const float a = yr[g], c = yi[g];
+            acc += a * a + c * c;
+        }
+    }
 
     if (nk_total == 0 && grad) {
         float* gr = grad + (size_t)frame * fsz;
@@ -249,13 +311,15 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
         const int nk = min(nkc, nk_total - g0);
         forward_rows(L, xr, xi, rowlist, g0, nk);
         // residual, loss, adjoint input 2 * (-1)^(ky+kx) * r  (the row sign is already in Rk)
+#pragma unroll 4
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
             const int j = e / MRI_R, kx = e - j * MRI_R;
-            const int ky = rowlist[g0 + j];
+            const int ky = L.rowl[g0 + j];
             const float sx = sgn(kx), sy = sgn(ky);
+            const float ya = yr[ky * MRI_R + kx], yb = yi[ky * MRI_R + kx];
             const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
-            const float rr = sx * v.x - yr[(size_t)ky * MRI_R + kx];
-            const float ri = sx * v.y - yi[(size_t)ky * MRI_R + kx];
+            const float rr = sx * v.x - ya;
+            const float ri = sx * v.y - yb;
             acc += rr * rr + ri * ri;
             const float s = cs2 * sx * sy;
             L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
@@ -288,7 +352,7 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
         const int nk = min(nkc, nk_total - g0);
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
             const int j = e / MRI_R, kx = e - j * MRI_R;
-            const int ky = rowlist[g0 + j];
+            const int ky = L.rowl[g0 + j];
             const float s = sgn(kx) * sgn(ky);
             L.Rk[(size_t)j * MRI_RS + kx] =
                 c_make(s * gr[(size_t)ky * MRI_R + kx], s * gi[(size_t)ky * MRI_R + kx]);
