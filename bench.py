@@ -43,6 +43,19 @@ def parse():
     return p.parse_args()
 
 
+def measured_traffic(kernel, matches):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json; FETCH_SIZE/WRITE_SIZE cannot be collected from inside this
+    process).  Only returned when the profiled configuration is the one being run."""
+    if not matches:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def event_ms(pairs):
     return [a.elapsed_time(b) for a, b in pairs]
 
@@ -159,7 +172,8 @@ def main():
             dom = max(per, key=lambda k: per[k]["ms"])
             roof = dict(bound="mfma", kernel=dom + "_" + op.path, achieved=per[dom]["tflops"],
                         peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS, traffic=None,
+                        frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+                        traffic=measured_traffic("k_" + dom + "_sep", op.path == "sep" and B == 64),
                         algorithmic="4*T*F*H*W flop per chain per direction x %d chains" % B,
                         kernels_ms=kern,
                         other={k: v["tflops"] for k, v in per.items() if k != dom})
@@ -167,7 +181,8 @@ def main():
             byts = 24.0 * 12 * 192 * 192 * B                  # read x, read y, write grad
             gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                        traffic=measured_traffic("k_mri_loss_grad", B == 32),
                         algorithmic="24*T*R*R bytes per chain x %d chains" % B, kernels_ms=kern)
         out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
                    unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
