@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../step_amd/csrc"
 mkdir -p ../../variants /tmp/var_$1
-for f in bh_dft_dense bh_dft_sep bh_closure mri_fft mcmc_update; do
+for f in bh_dft_dense bh_dft_sep bh_dft_sep3 bh_closure mri_fft mcmc_update; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $2 -c $f.hip -o /tmp/var_$1/$f.o &
 done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $2 -x hip -c tables.cpp -o /tmp/var_$1/tables.o &

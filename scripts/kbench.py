@@ -11,7 +11,8 @@ from step_amd import eht_lite
 from step_amd.forward_operator import BlackHoleImagingTorch
 dev = 'cuda:0'
 tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
-op = BlackHoleImagingTorch(imsize=256, ref_multiplier=0.001, device=dev, obs_table=tab, w_flux=0.26)
+op = BlackHoleImagingTorch(imsize=256, ref_multiplier=0.001, device=dev, obs_table=tab, w_flux=0.26,
+                           dft=os.environ.get('KB_DFT', 'auto'))
 B = int(os.environ.get('KB_B', '64'))
 x = torch.rand(B, 64, 1, 256, 256, device=dev) * 2 - 1
 gv = torch.randn(B, 64 * 28, 2, device=dev); gf = torch.randn(B, 64, device=dev)
@@ -27,4 +28,4 @@ def timeit(fn, n=20):
 fm, f0 = timeit(lambda: op._dft(x, 0.5, 0.5, float('-inf')))
 am, a0 = timeit(lambda: op._adjoint(gv, gf, None, 0.5))
 fl = 4.0 * 64 * 28 * 65536 * B
-print('%-28s fwd med %.3f ms (%.1f TF) min %.3f | adj med %.3f ms (%.1f TF) min %.3f' % (os.path.basename(lib_path), fm, fl / fm / 1e9, f0, am, fl / am / 1e9, a0))
+print('%-22s %-5s fwd med %.3f ms (%.1f TF) min %.3f | adj med %.3f ms (%.1f TF) min %.3f' % (os.path.basename(lib_path), op.path, fm, fl / fm / 1e9, f0, am, fl / am / 1e9, a0))

@@ -3,9 +3,11 @@ interface (reference forward_operator/blackhole.py): registry name ``'blackhole'
 constructor kwargs, ``__call__`` / ``loss`` / ``gradient`` / ``evaluate_chisq`` and the
 ``BlackHoleObservation`` measurement container.
 
-Two kernel paths compute the same contraction vis = A_vis x:
-  * ``sep``   -- A_vis is kept as its rank-1 factors (what ehtim's ftmatrix produces), never
-                 materialised; used when the operator is built from uv coordinates;
+Three kernel paths compute the same contraction vis = A_vis x:
+  * ``sep3``  -- A_vis kept as its rank-1 factors (what ehtim's ftmatrix produces), never
+                 materialised; fp32 operands split exactly into three bf16 planes for the bf16
+                 matrix cores (HBM-bound).  Default for square 256 / 128 / 64 / 32 images;
+  * ``sep``   -- the same factors on the fp32 matrix cores (any H, W multiple of 32 up to 512);
   * ``dense`` -- an arbitrary complex A_vis tensor (``from_tensors``), packed once for MFMA.
 The set-up that the reference delegates to ehtim (array file -> uv, sigma, closure sets) is
 done by ``step_amd.eht_lite`` (PARITY UNPINNED, see there); pass ``obs_table=`` to supply it.
@@ -121,7 +123,8 @@ class _VisFn(torch.autograd.Function):
 class BlackHoleImagingTorch(Operator):
     def __init__(self, array="configs/task/EHT2017.txt", imsize=256, w_vis=0, w_amp=0,
                  w_cphase=1, w_logcamp=1, w_flux=0.5, loss_normalize=True, num_frames=64,
-                 ref_multiplier=1.0, device='cuda', obs_table=None, force_dense=False):
+                 ref_multiplier=1.0, device='cuda', obs_table=None, force_dense=False,
+                 dft='auto'):
         super().__init__(0)
         assert num_frames == 64, "num_frames should be 64"
         table = obs_table if obs_table is not None else eht_lite.eht_table(array)
@@ -138,8 +141,16 @@ class BlackHoleImagingTorch(Operator):
         self._init_common(T, F, imsize, imsize, sigma, cp_i, cp_c, ca_i, ca_c, w_vis, w_amp,
                           w_cphase, w_logcamp, w_flux, loss_normalize)
         sep_ok = (F <= 31 and imsize % 32 == 0 and imsize <= 512)
-        if sep_ok and not force_dense:
+        assert dft in ("auto", "sep3", "sep", "dense"), dft
+        if force_dense:
+            dft = "dense"
+        if sep_ok and dft != "dense":
             self._init_sep(ey, ex)
+            sep3_ok = bool(_lib.lib().bh_sep3_supported(imsize, imsize))
+            if dft == "sep3" and not sep3_ok:
+                raise ValueError("dft='sep3' is built for square 256/128/64/32 images only")
+            if dft in ("auto", "sep3") and sep3_ok:
+                self.path = "sep3"
         else:
             A = torch.from_numpy(eht_lite.dense_from_factors(ey, ex)).to(torch.complex64)
             self._init_dense(A.to(self.device))
@@ -299,10 +310,11 @@ class BlackHoleImagingTorch(Operator):
         flux = torch.empty(B, self.T, device=self.device, dtype=torch.float32)
         L, st = _lib.lib(), _lib.stream_of(xv)
         t0 = self._tick()
-        if self.path == "sep":
-            rc = L.bh_dft_fwd_sep(self._ey_t.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
-                                  self.H, self.W, xv.data_ptr(), B, scale, shift, clip_min,
-                                  vis.data_ptr(), flux.data_ptr(), st)
+        if self.path in ("sep", "sep3"):
+            fn = L.bh_dft_fwd_sep3 if self.path == "sep3" else L.bh_dft_fwd_sep
+            rc = fn(self._ey_t.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                    self.H, self.W, xv.data_ptr(), B, scale, shift, clip_min,
+                    vis.data_ptr(), flux.data_ptr(), st)
         else:
             HW = self.H * self.W
             ws = torch.empty(L.bh_dense_fwd_workspace_floats(self.T, self.F, HW, B),
@@ -321,10 +333,11 @@ class BlackHoleImagingTorch(Operator):
         L, st = _lib.lib(), _lib.stream_of(grad)
         cs = None if chain_scale is None else chain_scale.data_ptr()
         t0 = self._tick()
-        if self.path == "sep":
-            rc = L.bh_dft_adj_sep(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
-                                  self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
-                                  out_scale, grad.data_ptr(), st)
+        if self.path in ("sep", "sep3"):
+            fn = L.bh_dft_adj_sep3 if self.path == "sep3" else L.bh_dft_adj_sep
+            rc = fn(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                    self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
+                    out_scale, grad.data_ptr(), st)
         else:
             rc = L.bh_dft_adj_dense(self._a_rows.data_ptr(), self.T, self.F, self.H * self.W,
                                     gvis.data_ptr(), gflux.data_ptr(), cs, B, out_scale,

@@ -143,13 +143,14 @@ def test_measurement_batch_broadcast_and_chain_independence(golden, dev):
 
 
 # ------------------------------------------------------------------ separable path vs oracle
-def sep_setup(n_sites, imsize, dev, seed=5, sigma_scale=1e-3, **kw):
+def sep_setup(n_sites, imsize, dev, seed=5, sigma_scale=1e-3, dft="auto", **kw):
     from step_amd import eht_lite
     from step_amd.forward_operator import BlackHoleImagingTorch
     tab = eht_lite.synthetic_table(n_sites, 64, seed=seed, sigma_scale=sigma_scale)
     wk = dict(w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.26, loss_normalize=True)
     wk.update(kw)
-    op = BlackHoleImagingTorch(imsize=imsize, ref_multiplier=0.001, device=dev, obs_table=tab, **wk)
+    op = BlackHoleImagingTorch(imsize=imsize, ref_multiplier=0.001, device=dev, obs_table=tab,
+                               dft=dft, **wk)
     A = np.stack([eht_synth.ftmatrix_dense(eht_synth.PSIZE, imsize, imsize, tab["uv"][i])
                   for i in range(64)])
     orc = BlackholeOracle(torch.from_numpy(A).to(torch.complex64).unsqueeze(0), op.sigma.cpu(),
@@ -158,12 +159,15 @@ def sep_setup(n_sites, imsize, dev, seed=5, sigma_scale=1e-3, **kw):
     return op, orc, tab
 
 
-@pytest.mark.parametrize("n_sites,imsize,B", [(4, 32, 3), (8, 64, 2), (7, 96, 1)])
-def test_sep_matches_oracle(n_sites, imsize, B, dev):
+@pytest.mark.parametrize("n_sites,imsize,B,dft", [
+    (4, 32, 3, "sep3"), (4, 32, 3, "sep"), (8, 64, 2, "sep3"), (8, 64, 2, "sep"), (7, 96, 1, "sep"),
+    (5, 128, 3, "sep3")])
+def test_sep_matches_oracle(n_sites, imsize, B, dft, dev):
+    """Both separable paths (3 x bf16 planes / fp32 matrix cores) against the CPU oracle; odd B
+    exercises the half-filled last chain pair of the persistent forward."""
     from step_amd.forward_operator import BlackHoleObservation
-    assert_sep = sep_setup(n_sites, imsize, dev, sigma_scale=1e-3 * imsize / 32)
-    op, orc, _ = assert_sep
-    assert op.path == "sep"
+    op, orc, _ = sep_setup(n_sites, imsize, dev, sigma_scale=1e-3 * imsize / 32, dft=dft)
+    assert op.path == dft
     gen = torch.Generator().manual_seed(11)
     x_gt = torch.rand(B, 64, 1, imsize, imsize, generator=gen) * 2 - 1
     x = torch.rand(B, 64, 1, imsize, imsize, generator=gen) * 2 - 1
@@ -188,7 +192,8 @@ def test_sep_equals_dense_path(dev):
     kw = dict(imsize=64, ref_multiplier=0.001, device=dev, obs_table=tab, w_vis=0.2, w_amp=0.3,
               w_flux=0.26)
     a, b = BlackHoleImagingTorch(**kw), BlackHoleImagingTorch(force_dense=True, **kw)
-    assert (a.path, b.path) == ("sep", "dense")
+    c = BlackHoleImagingTorch(dft="sep", **kw)
+    assert (a.path, b.path, c.path) == ("sep3", "dense", "sep")
     gen = torch.Generator().manual_seed(3)
     x = (torch.rand(5, 64, 1, 64, 64, generator=gen) * 2 - 1).to(dev)
     y = a((torch.rand(1, 64, 1, 64, 64, generator=gen) * 2 - 1).to(dev))
@@ -198,6 +203,9 @@ def test_sep_equals_dense_path(dev):
     assert_close(la, lb, RTOL, "loss")
     assert_close(ga, gb, RTOL, "gradient")
     assert_close(a.A_vis, b.A_vis, 1e-6, "A_vis attribute")
+    gc, lc = c.gradient(x, y, return_loss=True)
+    assert_close(lc, lb, RTOL, "loss (fp32 sep)")
+    assert_close(gc, gb, RTOL, "gradient (fp32 sep)")
 
 
 # ------------------------------------------------------------------ full size (BASELINE shapes)
@@ -210,8 +218,8 @@ def full_inputs(g):
     return x_gt, x, x_near
 
 
-@pytest.mark.parametrize("force_dense", [False, True])
-def test_full_size_matches_golden(force_dense, golden, dev):
+@pytest.mark.parametrize("dft", ["sep3", "sep", "dense"])
+def test_full_size_matches_golden(dft, golden, dev):
     """64 x 256 x 256, 8 stations (F=28, K_cp=1344, K_ca=1280): the reference's own outputs."""
     from step_amd import eht_lite
     from step_amd.forward_operator import BlackHoleImagingTorch
@@ -219,7 +227,8 @@ def test_full_size_matches_golden(force_dense, golden, dev):
     tab = eht_lite.synthetic_table(8, 64, seed=int(g["seed"]), sigma_scale=float(g["sigma_scale"]))
     assert np.array_equal(tab["uv"], g["uv"])
     op = BlackHoleImagingTorch(imsize=256, ref_multiplier=0.001, device=dev, obs_table=tab,
-                               force_dense=force_dense, **weights_kw(g))
+                               dft=dft, **weights_kw(g))
+    assert op.path == dft
     assert torch.equal(op.cp_index.cpu(), t(g["cp_index"]))
     assert torch.equal(op.camp_conjugate.cpu(), t(g["camp_conjugate"]))
     y = make_y(g, dev)
@@ -247,6 +256,7 @@ def test_full_size_properties_batch64(dev):
     tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
     op = BlackHoleImagingTorch(imsize=256, ref_multiplier=0.001, device=dev, obs_table=tab,
                                w_flux=0.26)
+    assert op.path == "sep3"
     gen = torch.Generator(device=dev).manual_seed(1)
     x1 = torch.rand(64, 64, 1, 256, 256, device=dev, generator=gen)
     x2 = torch.rand(64, 64, 1, 256, 256, device=dev, generator=gen)
