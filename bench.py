@@ -7,7 +7,8 @@ A "step" is one pass of the hot path over one batch of synthetic chains: for eve
 Langevin data step = operator loss forward + adjoint (``operator.gradient(x, y, return_loss=True)``,
 reference sampler/daps.py:100) at the shapes of configs/task/*.yaml.  The default workload is
 BASELINE.json configs[1]: the black-hole operator, 64 x 1 x 256 x 256 video, 8 stations (F = 28,
-K_cp = 1344, K_ca = 1280), B = 64 chains per GPU (config 4's num_samples), separable MFMA path.
+K_cp = 1344, K_ca = 1280), B = 64 chains per GPU (config 4's num_samples), separable path on the
+bf16 matrix cores (exact 3-plane operand split, folded image: step_amd/csrc/bh_dft_sep3.hip).
 Inputs are resident in HBM before the timed region.  value = chain-steps / s over all GPUs.
 
 Multi-GPU: chains are independent, so each rank runs its own B chains (weak scaling) with no
@@ -33,11 +34,13 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md, HBM3E spec peak
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    # a step is ~0.5 ms: the defaults run long enough to leave the clock ramp of an idle GPU
+    # (the first ~15 ms of MFMA work run 20 % slower than steady state) inside the warm-up
+    p.add_argument("--steps", type=int, default=400)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--task", default="blackhole", choices=["blackhole", "mri"])
     p.add_argument("--batch", type=int, default=None, help="chains per GPU (64 blackhole, 32 mri)")
-    p.add_argument("--path", default="sep", choices=["sep", "dense"])
+    p.add_argument("--path", default="auto", choices=["auto", "sep3", "sep", "dense"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=8)
     return p.parse_args()
@@ -45,15 +48,18 @@ def parse():
 
 def measured_traffic(kernel, matches):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json; FETCH_SIZE/WRITE_SIZE cannot be collected from inside this
+    (newest profiles/r*_traffic.json that has the kernel; FETCH_SIZE/WRITE_SIZE cannot be collected from inside this
     process).  Only returned when the profiled configuration is the one being run."""
     if not matches:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def event_ms(pairs):
@@ -66,7 +72,7 @@ def build_blackhole(dev, path):
     tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
     op = BlackHoleImagingTorch(imsize=256, w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.26,
                                loss_normalize=True, num_frames=64, ref_multiplier=0.001, device=dev,
-                               obs_table=tab, force_dense=(path == "dense"))
+                               obs_table=tab, dft=path)
     return op, tab
 
 
@@ -170,13 +176,26 @@ def main():
             flop = 4.0 * T * F * HW * B                       # per direction per launch
             per = {k: dict(ms=kern[k], tflops=flop / (kern[k] * 1e-3) / 1e12) for k in ("dft_fwd", "dft_adj")}
             dom = max(per, key=lambda k: per[k]["ms"])
-            roof = dict(bound="mfma", kernel=dom + "_" + op.path, achieved=per[dom]["tflops"],
-                        peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
-                        traffic=measured_traffic("k_" + dom + "_sep", op.path == "sep" and B == 64),
-                        algorithmic="4*T*F*H*W flop per chain per direction x %d chains" % B,
-                        kernels_ms=kern,
-                        other={k: v["tflops"] for k, v in per.items() if k != dom})
+            if op.path == "sep3":
+                # the bf16 matrix work (6 plane products on half the rows) fits under the one pass
+                # over the image that each direction must make: the kernel is HBM-bound
+                byts = 4.0 * T * HW * B                       # fwd: read x; adj: write grad
+                gbs = byts / (per[dom]["ms"] * 1e-3) / 1e9
+                roof = dict(bound="hbm", kernel=dom + "_sep3", achieved=gbs, peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                            traffic=measured_traffic("k_" + dom + "_s3", B == 64),
+                            algorithmic="4*T*H*W bytes per chain per direction x %d chains" % B,
+                            kernels_ms=kern,
+                            fp32_equivalent_tflops={k: v["tflops"] for k, v in per.items()},
+                            other_gbs={k: byts / (v["ms"] * 1e-3) / 1e9 for k, v in per.items() if k != dom})
+            else:
+                roof = dict(bound="mfma", kernel=dom + "_" + op.path, achieved=per[dom]["tflops"],
+                            peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+                            traffic=measured_traffic("k_" + dom + "_sep", op.path == "sep" and B == 64),
+                            algorithmic="4*T*F*H*W flop per chain per direction x %d chains" % B,
+                            kernels_ms=kern,
+                            other={k: v["tflops"] for k, v in per.items() if k != dom})
         else:
             byts = 24.0 * 12 * 192 * 192 * B                  # read x, read y, write grad
             gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9

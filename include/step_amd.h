@@ -113,11 +113,15 @@ int bh_dft_adj_sep(const float* ey_ri, const float* ex_ri, int T, int F, int H, 
 
 /* The same two contractions (same tables, same arguments, same reference lines) on the bf16
  * matrix cores: every fp32 operand is split exactly into three bf16 planes in-kernel and the six
- * leading plane products are accumulated in fp32 (error <= one fp32 rounding per product, see
- * DESIGN.md).  HBM-bound instead of fp32-MFMA-bound.  Built for the square sizes
- * bh_sep3_supported() accepts (256, 128, 64, 32); other shapes return STEP_E_INVALID -- use the
- * fp32 entry points above for them.  Inputs with Inf pixels give NaN (Inf - Inf in the split). */
+ * leading plane products are accumulated in fp32 (error <= one fp32 rounding per product), and
+ * the image is folded about its horizontal mid-line, which needs ey[f][H-1-y] == conj(ey[f][y])
+ * bit for bit (true for ehtim's centred pixel grid; bh_sep3_tables_ok checks a host copy of
+ * ey_ri -- the kernels cannot, and give wrong results on other tables).  HBM-bound instead of
+ * fp32-MFMA-bound.  Built for the square sizes bh_sep3_supported() accepts (256, 128, 64);
+ * other shapes return STEP_E_INVALID -- use the fp32 entry points above for them.  Inputs with
+ * Inf pixels give NaN (Inf - Inf in the split). */
 int bh_sep3_supported(int H, int W);
+int bh_sep3_tables_ok(const float* ey_ri_host, int T, int H);
 int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int F, int H, int W,
                     const float* x, int B, float scale, float shift, float clip_min,
                     float* vis_c64, float* flux, void* stream);

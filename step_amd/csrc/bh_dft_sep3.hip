@@ -1,34 +1,47 @@
-// Separable black-hole DFT with fp32 operands split into three bf16 planes ("3xbf16").
+// Separable black-hole DFT on the bf16 matrix cores: fp32 operands split exactly into three
+// bf16 planes ("3 x bf16"), and the image folded about its horizontal mid-line.
 //
 // Same contraction as bh_dft_sep.hip (ehtim ftmatrix is rank-1 per baseline, blackhole.py:226,
-// forward blackhole.py:315-321), but the matrix cores run v_mfma_f32_32x32x16_bf16 (16x the
-// fp32 MFMA rate) on an EXACT decomposition of every fp32 operand
-//     a = a_hi + a_mid + a_lo        (8 + 8 + 8 mantissa bits, by truncation, all three bf16)
-// and accumulate the six products whose weight is >= 2^-16 of the leading one
-//     a x  ~=  a_hi x_hi + (a_hi x_mid + a_mid x_hi) + (a_hi x_lo + a_mid x_mid + a_lo x_hi)
-// in fp32.  Every bf16 x bf16 product is exact in fp32; the dropped terms are <= 3 * 2^-24 of
-// |a x|, i.e. the size of ONE fp32 rounding of the product, and ten times below the rounding
-// noise of any fp32 sum over 65536 pixels (measured: oracle/README note in DESIGN.md section 4).
-// Six bf16 MFMAs cost 6/16 of the fp32 MFMA they replace, which moves both directions off the
-// fp32-matrix roofline onto the HBM roofline (one read of x / one write of grad).
+// forward blackhole.py:315-321).  Two ideas on top of it:
 //
-// forward: persistent workgroups of 16 waves.  A workgroup owns frame t for `cpw` chains: it
-//   splits the frame's ey table into bf16 planes in LDS ONCE (96 KB at H = 256) and then walks
-//   its chains two at a time (waves 0-7: chain b, waves 8-15: chain b + 1; one 32-column strip
-//   per wave).  The leading products go to `main`, the five corrections to `small`: the
-//   corrections are 2^-8 of the leading term, so their rounding never matters, and `main`
-//   sees only H/16 additions per output -- the short-chain discipline of the fp32 kernel
-//   without its extra adds.
-// adjoint: one workgroup (8 waves) per (chain, frame, half of the rows): G[k][y] (g folded into
-//   conj(ey)) is built straight into bf16 planes in LDS, the ex rows of the strip are split
-//   once into registers, and each 32x32 output tile takes <= 24 bf16 MFMAs before its 16 row
-//   stores.
+// 1. Operand split.  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate.  Every fp32
+//    operand is decomposed EXACTLY (by truncation) into three bf16 values
+//        a = a_hi + a_mid + a_lo        (8 + 8 + 8 mantissa bits)
+//    and the six products whose weight is >= 2^-16 of the leading one
+//        a x ~= a_hi x_hi + (a_hi x_mid + a_mid x_hi) + (a_hi x_lo + a_mid x_mid + a_lo x_hi)
+//    are accumulated in fp32.  A bf16 x bf16 product is exact in fp32; the dropped terms are
+//    <= 3 * 2^-24 |a x|, the size of ONE fp32 rounding of the product and ten times below the
+//    rounding noise of any fp32 sum over 65536 pixels.
+//
+// 2. Fold.  ehtim's pixel grid is centred, so ey[f][H-1-y] = conj(ey[f][y]) (bit-exact in the
+//    fp32 tables; the caller checks it, bh_sep3_tables_ok).  Re ey is even and Im ey is odd in y:
+//        Re Z[f][x] = sum_{y < H/2} Re ey[f][y] (X[y][x] + X[H-1-y][x])
+//        Im Z[f][x] = sum_{y < H/2} Im ey[f][y] (X[y][x] - X[H-1-y][x])
+//    and for the adjoint, with w[f][x] = conj(ex[f][x]) g[f],
+//        E[y][x] = sum_f Re ey[f][y] Re w[f][x],   O[y][x] = sum_f Im ey[f][y] Im w[f][x]
+//        grad[y][x] = E + O,   grad[H-1-y][x] = E - O          (y < H/2)
+//    which halves the matrix work and the LDS image of ey in both directions, and makes the
+//    adjoint's LDS operand independent of the chain (g moves into the register operand).
+//
+// Both kernels are persistent: a workgroup (8 waves, one 32-column strip each) owns frame t for
+// `cpw` chains, stages the frame's ey planes in LDS once (48 KB at H = 256) and walks its chains.
+// forward: a ring of R blocks (16 rows from the top + their 16 mirror rows, 16 dwords per lane
+//   per block) keeps R - 1 blocks in flight across chain boundaries; the leading products go to
+//   `mn`, the five corrections to `sm` (2^-8 of the leading term, their rounding never matters),
+//   so `mn` sees H/32 additions per output.  Epilogue: complex multiply by ex in the
+//   accumulator layout, DPP row sums, fixed-order sum over strips.
+// adjoint: per chain each wave folds g into its ex columns (w), splits w into planes in
+//   registers, and produces two mirrored 32x32 output tiles from 24 MFMAs; no barrier in the
+//   chain loop.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define S3_ADJ_THREADS 512
+#define S3_THREADS 512
+#ifndef S3_RING
+#define S3_RING 4
+#endif
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -58,17 +71,12 @@ __device__ __forceinline__ f32x16 s3_fake(u32x4 a, u32x4 b, f32x16 c) {
 }
 #define S3_MFMA(a, b, c) s3_fake(a, b, c)
 #endif
-#ifndef EXP3_NOSPLIT
-#define S3_SPLIT(v, a, b, c) split3(v, a, b, c)
-#else   // timing experiment: no operand split (wrong numbers)
-#define S3_SPLIT(v, a, b, c)                                                              \
-    {                                                                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                \
-            a[j_] = __float_as_uint(v[2 * j_]); b[j_] = __float_as_uint(v[2 * j_ + 1]);   \
-            c[j_] = a[j_];                                                                \
-        }                                                                                 \
-    }
-#endif
+
+// the six plane products of one operand pair: corrections into sm, leading term into mn
+#define S3_SIX(ah, am, al, bh, bm, bl, sm, mn)                  \
+    sm = S3_MFMA(al, bh, sm); sm = S3_MFMA(ah, bl, sm);         \
+    sm = S3_MFMA(am, bm, sm); sm = S3_MFMA(am, bh, sm);         \
+    sm = S3_MFMA(ah, bm, sm); mn = S3_MFMA(ah, bh, mn);
 
 // sum over the 16 lanes of a DPP row; lane 0 of the row adds in a fixed order
 __device__ __forceinline__ float row16_sum(float v) {
@@ -81,87 +89,114 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+static int s3_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
+// chains per workgroup: one resident workgroup per CU, every CU busy, no second round
+static void s3_grid(int B, int T, int* cpw, int* gx) {
+    int per_t = s3_cu_count() / T;
+    per_t = per_t < 1 ? 1 : (per_t > B ? B : per_t);
+    *cpw = (B + per_t - 1) / per_t;
+    *gx = (B + *cpw - 1) / *cpw;
+}
+
+extern "C" int bh_sep3_supported(int H, int W) {
+    return (H == 256 && W == 256) || (H == 128 && W == 128) || (H == 64 && W == 64);
+}
+
+// Host check of the fold's precondition on the planar table ey_ri [T][2][32][H] (host memory):
+// Re ey even, Im ey odd about the horizontal mid-line, bit for bit.
+extern "C" int bh_sep3_tables_ok(const float* ey_ri_host, int T, int H) {
+    if (!ey_ri_host || T <= 0 || H <= 0) return 0;
+    for (int t = 0; t < T; ++t)
+        for (int f = 0; f < 32; ++f) {
+            const float* re = ey_ri_host + (((size_t)t * 2 + 0) * 32 + f) * H;
+            const float* im = ey_ri_host + (((size_t)t * 2 + 1) * 32 + f) * H;
+            for (int y = 0; y < H / 2; ++y)
+                if (re[y] != re[H - 1 - y] || im[y] != -im[H - 1 - y]) return 0;
+        }
+    return 1;
+}
+
 // ------------------------------------------------------------------------------- forward
-// LDS: ey planes, 16-byte units [(kb*3 + plane)*2 + h][64 rows] (kb = 16-row block of y, rows =
-// Re f | Im f): the A fragment of lane (row, h) for k = 16 kb + 8 h + 0..7 is one ds_read_b128,
-// consecutive lanes read consecutive units.  Then sred [parity][chain slot][2 * strips][64].
-// NFR = chains in flight per workgroup (8 waves each); R = ring of 16-row blocks per wave
-// (R - 1 blocks of 8 dwords per lane are in flight while one is consumed; the ring runs on
-// across chains, so the stream never drains inside a workgroup).
-#ifndef S3_NFR
-#define S3_NFR 1
-#endif
-#ifndef S3_RING
-#define S3_RING 4
-#endif
-template <int H, int W, int NFR, int R, bool CLIP>
-__global__ __launch_bounds__(512 * NFR, 1) void k_dft_fwd_s3(
+// LDS: ey planes, 16-byte units [((kb*2 + part)*3 + plane)*2 + h][32 rows f] (kb = block of 16
+// rows of the upper half, part 0 = Re ey, 1 = Im ey): the A fragment of lane (f, h) for
+// k = 16 kb + 8 h + 0..7 is one ds_read_b128, consecutive lanes read consecutive units.
+// Then sred [parity][2 * strips][64].
+template <int H, int W, int R, bool CLIP>
+__global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     const float* __restrict__ ey_t, const float* __restrict__ ex_ri, const float* __restrict__ x,
     float* __restrict__ vis, float* __restrict__ flux, int T, int F, int B, int cpw, float scale,
     float shift, float clip_min) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
-    constexpr int NKB = H / 16, NSTRIP = W / 32, NPART = 2 * NSTRIP, NTHR = 512 * NFR;
+    constexpr int NKB = H / 32, NSTRIP = W / 32, NPART = 2 * NSTRIP;
     static_assert(NKB % R == 0, "ring must divide the block count");
     u32x4* eyp = lds4;
-    float* sred = (float*)(lds4 + NKB * 3 * 2 * 64);
+    float* sred = (float*)(lds4 + NKB * 384);
     const int t = blockIdx.y, b0 = blockIdx.x * cpw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = wave >> 3, strip = wave & 7;
+    const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
+    const int n_it = min(cpw, B - b0);
 
-    for (int u = tid; u < (H / 8) * 64; u += NTHR) {
-        const int row = u & 63, yg = u >> 6;                 // yg = 2 kb + h
-        const float* src = ey_t + ((size_t)t * H + yg * 8) * 64 + row;
+    for (int u = tid; u < (H / 16) * 64; u += S3_THREADS) {
+        const int col = u & 63, yg = u >> 6;                 // col = part*32 + f, yg = 2 kb + h
+        const float* src = ey_t + ((size_t)t * H + yg * 8) * 64 + col;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[j * 64];
         u32x4 p0, p1, p2;
         split3(v, p0, p1, p2);
-        const int kb = yg >> 1, hh = yg & 1;
-        eyp[((kb * 3 + 0) * 2 + hh) * 64 + row] = p0;
-        eyp[((kb * 3 + 1) * 2 + hh) * 64 + row] = p1;
-        eyp[((kb * 3 + 2) * 2 + hh) * 64 + row] = p2;
+        const int kb = yg >> 1, hh = yg & 1, part = col >> 5, f = col & 31;
+        u32x4* dst = eyp + (((kb * 2 + part) * 3) * 2 + hh) * 32 + f;
+        dst[0] = p0; dst[64] = p1; dst[128] = p2;
     }
     __syncthreads();
 
     const bool mine = strip < NSTRIP;                        // W < 256: the spare waves idle
     const int xcol = (mine ? strip : 0) * 32 + li;
-    const u32x4* ap = eyp + h * 64 + li;
+    const u32x4* ap = eyp + h * 32 + li;
     const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W + xcol;
     const float* exi = ex_ri + ((size_t)t * 2 + 1) * 32 * W + xcol;
-    const int n_it = cpw / NFR;
     const size_t frame = (size_t)H * W;
-    auto frame_ptr = [&](int it) {
-        const int b = min(b0 + NFR * it + fr, B - 1);        // past-the-end slots redo chain B-1
-        return x + ((size_t)b * T + t) * frame + 8 * h * W + xcol;
-    };
+    // pointer to row 8h of the chain's frame; the mirror rows are addressed from it too
+    auto frame_ptr = [&](int it) { return x + ((size_t)(b0 + it) * T + t) * frame + 8 * h * W + xcol; };
 
     f32x16 mn0, mn1, sm0, sm1;
-    float xq[R][8];
-#define S3_LOAD(dst, p, kb)                                                         \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) dst[j] = (p)[((kb) * 16 + j) * W];
-#define S3_COMPUTE(src, kb)                                                         \
-    {                                                                               \
-        float pv[8];                                                                \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                             \
-            pv[j] = fmaf(src[j], scale, shift);                                     \
-            if (CLIP) pv[j] = pv[j] < clip_min ? clip_min : pv[j];                  \
-        }                                                                           \
-        u32x4 xh, xm, xl;                                                           \
-        S3_SPLIT(pv, xh, xm, xl);                                                   \
-        const u32x4* a = ap + (kb) * (3 * 2 * 64);                                  \
-        {                                                                           \
-            const u32x4 ah = a[0], am = a[128], al = a[256];                        \
-            sm0 = S3_MFMA(al, xh, sm0); sm0 = S3_MFMA(ah, xl, sm0);                 \
-            sm0 = S3_MFMA(am, xm, sm0); sm0 = S3_MFMA(am, xh, sm0);                 \
-            sm0 = S3_MFMA(ah, xm, sm0); mn0 = S3_MFMA(ah, xh, mn0);                 \
-        }                                                                           \
-        {                                                                           \
-            const u32x4 ah = a[32], am = a[160], al = a[288];                       \
-            sm1 = S3_MFMA(al, xh, sm1); sm1 = S3_MFMA(ah, xl, sm1);                 \
-            sm1 = S3_MFMA(am, xm, sm1); sm1 = S3_MFMA(am, xh, sm1);                 \
-            sm1 = S3_MFMA(ah, xm, sm1); mn1 = S3_MFMA(ah, xh, mn1);                 \
-        }                                                                           \
+    float xq[R][16];
+    // block kb of the frame at p: rows 16 kb + 8h + j (top) and H-1 - (16 kb + 8h + j) (mirror)
+#define S3_LOAD(dst, p, kb)                                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                  \
+        dst[j] = (p)[((kb) * 16 + j) * W];                                           \
+        dst[8 + j] = (p)[(H - 1 - 16 * h - (kb) * 16 - j) * W];                      \
+    }
+#define S3_COMPUTE(src, kb)                                                          \
+    {                                                                                \
+        float ev[8], od[8];                                                          \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                              \
+            float pt = fmaf(src[j], scale, shift), pb = fmaf(src[8 + j], scale, shift); \
+            if (CLIP) {                                                              \
+                pt = pt < clip_min ? clip_min : pt;                                  \
+                pb = pb < clip_min ? clip_min : pb;                                  \
+            }                                                                        \
+            ev[j] = pt + pb;                                                         \
+            od[j] = pt - pb;                                                         \
+        }                                                                            \
+        u32x4 eh, em, el, oh, om, ol;                                                \
+        split3(ev, eh, em, el);                                                      \
+        split3(od, oh, om, ol);                                                      \
+        const u32x4* a = ap + (kb) * 384;                                            \
+        {                                                                            \
+            const u32x4 ah = a[0], am = a[64], al = a[128];                          \
+            S3_SIX(ah, am, al, eh, em, el, sm0, mn0)                                 \
+        }                                                                            \
+        {                                                                            \
+            const u32x4 ah = a[192], am = a[256], al = a[320];                       \
+            S3_SIX(ah, am, al, oh, om, ol, sm1, mn1)                                 \
+        }                                                                            \
     }
 
     const float* xcur = frame_ptr(0);
@@ -183,8 +218,10 @@ __global__ __launch_bounds__(512 * NFR, 1) void k_dft_fwd_s3(
                     // wait before each use counts loads instead of draining them); past the
                     // last chain xnext == xcur and the extra blocks are simply not used
                     const int nb = kb + s + R - 1;
-                    const float* pn = nb < NKB ? xcur + nb * 16 * W : xnext + (nb - NKB) * 16 * W;
-                    S3_LOAD(xq[(s + R - 1) % R], pn, 0);
+                    const bool wrap = nb >= NKB;
+                    const float* pn = wrap ? xnext : xcur;
+                    const int kn = wrap ? nb - NKB : nb;
+                    S3_LOAD(xq[(s + R - 1) % R], pn, kn);
                     __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of the MFMAs
                     S3_COMPUTE(xq[s], kb + s);
                     __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +229,7 @@ __global__ __launch_bounds__(512 * NFR, 1) void k_dft_fwd_s3(
             }
             // p[f] = sum_x ex[f][x] Z[f][x] over the strip: complex multiply in the accumulator
             // layout, DPP sum over each 16-lane row, lanes 0/16/32/48 hand their halves to sred
-            float* sp = sred + (((it & 1) * NFR + fr) * NPART + strip * 2 + ((lane >> 4) & 1)) * 64;
+            float* sp = sred + ((it & 1) * NPART + strip * 2 + ((lane >> 4) & 1)) * 64;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = mfma32_row(r, h);
@@ -204,16 +241,14 @@ __global__ __launch_bounds__(512 * NFR, 1) void k_dft_fwd_s3(
             }
         }
         __syncthreads();
-        if (strip == 0) {                                    // first wave of the chain: fixed-order sum
-            const float* sp = sred + ((it & 1) * NFR + fr) * NPART * 64 + lane;
+        if (strip == 0) {                                    // wave 0: fixed-order sum over strips
+            const float* sp = sred + (it & 1) * NPART * 64 + lane;
             float s = 0.f;
 #pragma unroll
             for (int p = 0; p < NPART; ++p) s += sp[p * 64];
-            const int b = b0 + NFR * it + fr, c = lane >> 5, f = lane & 31;
-            if (b < B) {
-                if (f < F) vis[(((size_t)b * T + t) * F + f) * 2 + c] = s;
-                else if (f == F && c == 0) flux[(size_t)b * T + t] = s;
-            }
+            const int b = b0 + it, c = lane >> 5, f = lane & 31;
+            if (f < F) vis[(((size_t)b * T + t) * F + f) * 2 + c] = s;
+            else if (f == F && c == 0) flux[(size_t)b * T + t] = s;
         }
         xcur = xnext;
     }
@@ -221,36 +256,21 @@ __global__ __launch_bounds__(512 * NFR, 1) void k_dft_fwd_s3(
 #undef S3_COMPUTE
 }
 
-static int s3_cu_count() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    return n;
-}
-
-extern "C" int bh_sep3_supported(int H, int W) {
-    return (H == 256 && W == 256) || (H == 128 && W == 128) || (H == 64 && W == 64) || (H == 32 && W == 32);
-}
-
 template <int H, int W>
 static void launch_fwd_s3(const float* ey_t, const float* ex_ri, int T, int F, const float* x, int B,
                           float scale, float shift, float clip_min, float* vis, float* flux,
                           hipStream_t st) {
-    constexpr int NFR = S3_NFR, R = (H / 16 < S3_RING) ? H / 16 : S3_RING;
-    // chains per workgroup: one resident workgroup per CU, every CU busy, no second round
-    const int groups = (B + NFR - 1) / NFR;
-    int per_t = s3_cu_count() / T;
-    per_t = per_t < 1 ? 1 : (per_t > groups ? groups : per_t);
-    const int cpw = NFR * ((groups + per_t - 1) / per_t);
-    const int gx = (B + cpw - 1) / cpw;
-    const size_t lds = (size_t)(H / 16) * 3 * 2 * 64 * 16 + (size_t)2 * NFR * 2 * (W / 32) * 64 * 4;
+    constexpr int R = (H / 32 < S3_RING) ? H / 32 : S3_RING;
+    int cpw, gx;
+    s3_grid(B, T, &cpw, &gx);
+    const size_t lds = (size_t)(H / 32) * 384 * 16 + (size_t)2 * 2 * (W / 32) * 64 * 4;
     if (clip_min == -INFINITY) {
-        step_allow_lds((const void*)k_dft_fwd_s3<H, W, NFR, R, false>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, NFR, R, false>), dim3(gx, T), dim3(512 * NFR), lds, st,
+        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, false>, lds);
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false>), dim3(gx, T), dim3(S3_THREADS), lds, st,
                            ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
     } else {
-        step_allow_lds((const void*)k_dft_fwd_s3<H, W, NFR, R, true>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, NFR, R, true>), dim3(gx, T), dim3(512 * NFR), lds, st,
+        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, true>, lds);
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, true>), dim3(gx, T), dim3(S3_THREADS), lds, st,
                            ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
     }
 }
@@ -261,121 +281,134 @@ extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int
     STEP_REQUIRE(ey_t && ex_ri && x && vis_c64 && flux, "bh_dft_fwd_sep3: null pointer");
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_fwd_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
-    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_fwd_sep3: image %dx%d not built (256, 128, 64, 32 square)", H, W);
+    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_fwd_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
     hipStream_t st = (hipStream_t)stream;
     if (H == 256) launch_fwd_s3<256, 256>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
     else if (H == 128) launch_fwd_s3<128, 128>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
-    else if (H == 64) launch_fwd_s3<64, 64>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
-    else launch_fwd_s3<32, 32>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
+
+    else launch_fwd_s3<64, 64>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
     STEP_CHECK_LAUNCH("bh_dft_fwd_sep3");
     return STEP_OK;
 }
 
 // ------------------------------------------------------------------------------- adjoint
-// LDS: G planes, 16-byte units [(kb*3 + plane)*2 + h][HS rows y] (kb = 16-row block of k),
-// then g2 [2F + 2].  k rows: Re f | Im f | flux | zero pad, as in bh_dft_sep.hip.
-template <int H, int W, int YS>
-__global__ __launch_bounds__(S3_ADJ_THREADS, 2) void k_dft_adj_s3(
+// LDS: ey planes as the A operand (M = y of the upper half, K = f), 16-byte units
+// [(((part*2 + kb)*3 + plane)*2 + h)][H/2 rows y]; part 0 = Re ey (with the flux row f = F,
+// ey = 1), part 1 = Im ey; kb = block of 16 baselines.  B operand per chain in registers:
+// wR[f][x] = Re(conj(ex) g) = exR gR + exI gI,  wI[f][x] = Im(conj(ex) g) = exR gI - exI gR.
+template <int H, int W>
+__global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
-    const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, float out_scale) {
+    const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, int B, int cpw,
+    float out_scale) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
-    constexpr int HS = H / YS, NSTRIP = W / 32, NTILE = HS / 32;
-    const int nkb = (2 * F + 1 + 15) >> 4;                   // <= 4
-    u32x4* gp = lds4;
-    float* g2 = (float*)(lds4 + 4 * 3 * 2 * HS);
-    const int b = blockIdx.x, t = blockIdx.y, y0 = blockIdx.z * HS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
+    const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
+    u32x4* eyp = lds4;
+    const int t = blockIdx.y, b0 = blockIdx.x * cpw;
+    const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
+    const int n_it = min(cpw, B - b0);
 
-    for (int e = tid; e < 2 * F + 2; e += S3_ADJ_THREADS) {
-        float v = 0.f;
-        if (e < F) v = gvis[(((size_t)b * T + t) * F + e) * 2];
-        else if (e < 2 * F) v = gvis[(((size_t)b * T + t) * F + (e - F)) * 2 + 1];
-        else if (e == 2 * F) v = gflux[(size_t)b * T + t];
-        g2[e] = cs * v;
-    }
-    __syncthreads();
-    // G[k][y]: k < F: Re(conj(ey) g);  F <= k < 2F: Im(conj(ey) g);  k = 2F: gflux;  else 0
-    const float* eyr = ey_ri + ((size_t)t * 2 + 0) * 32 * H + y0;
-    const float* eyi = ey_ri + ((size_t)t * 2 + 1) * 32 * H + y0;
-    for (int u = tid; u < nkb * 2 * HS; u += S3_ADJ_THREADS) {
-        const int y = u % HS, kg = u / HS;                   // kg = 2 kb + h
+    for (int u = tid; u < 8 * HH; u += S3_THREADS) {
+        const int y = u % HH, q = u / HH;                    // q = (part*2 + kb)*2 + h
+        const int hh = q & 1, kb = (q >> 1) & 1, part = q >> 2;
+        const float* src = ey_ri + (((size_t)t * 2 + part) * 32 + kb * 16 + hh * 8) * H + y;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kg * 8 + j;
-            const bool im = k >= F;
-            const int f = min(im ? k - F : k, F);            // f = F: the flux row (ey = 1 + 0i)
-            const float a = eyr[f * H + y], c = eyi[f * H + y];
-            const float gr = g2[min(f, F - 1)], gi = g2[F + min(f, F - 1)];
-            float w = im ? a * gi - c * gr : a * gr + c * gi;
-            if (k >= 2 * F) w = (k == 2 * F) ? g2[2 * F] : 0.f;
-            v[j] = w;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = src[j * H];
         u32x4 p0, p1, p2;
         split3(v, p0, p1, p2);
-        const int kb = kg >> 1, hh = kg & 1;
-        gp[((kb * 3 + 0) * 2 + hh) * HS + y] = p0;
-        gp[((kb * 3 + 1) * 2 + hh) * HS + y] = p1;
-        gp[((kb * 3 + 2) * 2 + hh) * HS + y] = p2;
+        u32x4* dst = eyp + (((part * 2 + kb) * 3) * 2 + hh) * HH + y;
+        dst[0] = p0; dst[2 * HH] = p1; dst[4 * HH] = p2;
     }
     __syncthreads();
+    if (strip >= NSTRIP) return;                             // W < 256: no barrier below
 
-    const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W;
-    const float* exi = ex_ri + ((size_t)t * 2 + 1) * 32 * W;
-    float* gf = grad + ((size_t)b * T + t) * H * W + (size_t)y0 * W;
-    for (int strip = wave; strip < NSTRIP; strip += S3_ADJ_THREADS / 64) {
-        const int xcol = strip * 32 + li;
-        u32x4 bh[4], bm[4], bl[4];                           // EXK[k][x]: Re ex | Im ex | 1 | 0
+    const int xcol = strip * 32 + li;
+    // this lane's baselines f = 16 kb + 8 h + j and their ex values (chain independent)
+    float exr[16], exi[16];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            float v[8];
+    for (int q = 0; q < 16; ++q) {
+        const int f = (q >> 3) * 16 + 8 * h + (q & 7);
+        exr[q] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
+        exi[q] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
+    }
+    float gr[16], gi[16], gfl;
+#define S3_GLOAD(b)                                                                          \
+    {                                                                                        \
+        const float2* gp_ = (const float2*)gvis + ((size_t)(b) * T + t) * F;                 \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                     \
+            const int f = (q >> 3) * 16 + 8 * h + (q & 7);                                   \
+            const float2 g_ = gp_[min(f, F - 1)];                                            \
+            gr[q] = g_.x; gi[q] = g_.y;                                                      \
+        }                                                                                    \
+        gfl = gflux[(size_t)(b) * T + t];                                                    \
+    }
+    S3_GLOAD(b0);
+    const u32x4* ap = eyp + h * HH + li;
+#pragma unroll 1
+    for (int it = 0; it < n_it; ++it) {
+        const int b = b0 + it;
+        const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
+        u32x4 rh[2], rm[2], rl[2], ih[2], im[2], il[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float wr[8], wi[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = kb * 16 + 8 * h + j;
-                const bool im = k >= F;
-                const int f = min(im ? k - F : k, F);        // row F of ex_ri is 1 + 0i
-                const float* tab = (im && k < 2 * F) ? exi : exr;
-                const float w = tab[f * W + xcol];
-                v[j] = (k <= 2 * F) ? w : 0.f;
+                const int q = kb * 8 + j, f = kb * 16 + 8 * h + j;
+                const float a = cs * gr[q], c = cs * gi[q];
+                float vr = exr[q] * a + exi[q] * c, vi = exr[q] * c - exi[q] * a;
+                if (f >= F) { vr = (f == F) ? cs * gfl : 0.f; vi = 0.f; }
+                wr[j] = vr; wi[j] = vi;
             }
-            split3(v, bh[kb], bm[kb], bl[kb]);
+            split3(wr, rh[kb], rm[kb], rl[kb]);
+            split3(wi, ih[kb], im[kb], il[kb]);
         }
-        const u32x4* ap = gp + h * HS + li;
+        S3_GLOAD(min(b + 1, B - 1));                         // next chain's g rides under the tiles
+        float* gf = grad + ((size_t)b * T + t) * H * W + xcol;
 #pragma unroll 1
         for (int tile = 0; tile < NTILE; ++tile) {
-            f32x16 acc;
+            f32x16 ev, od;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) ev[r] = od[r] = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
                 if (kb < nkb) {
-                    const u32x4* a = ap + kb * (3 * 2 * HS) + tile * 32;
-                    const u32x4 ah = a[0], am = a[2 * HS], al = a[4 * HS];
-                    acc = S3_MFMA(al, bh[kb], acc);
-                    acc = S3_MFMA(ah, bl[kb], acc);
-                    acc = S3_MFMA(am, bm[kb], acc);
-                    acc = S3_MFMA(am, bh[kb], acc);
-                    acc = S3_MFMA(ah, bm[kb], acc);
-                    acc = S3_MFMA(ah, bh[kb], acc);
+                    const u32x4* a = ap + kb * (6 * HH) + tile * 32;
+                    {
+                        const u32x4 ah = a[0], am = a[2 * HH], al = a[4 * HH];
+                        S3_SIX(ah, am, al, rh[kb], rm[kb], rl[kb], ev, ev)
+                    }
+                    {
+                        const u32x4 ah = a[12 * HH], am = a[14 * HH], al = a[16 * HH];
+                        S3_SIX(ah, am, al, ih[kb], im[kb], il[kb], od, od)
+                    }
                 }
-            const int go = (tile * 32 + 4 * h) * W + xcol;
+            const int ytop = tile * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gf[go + ((r & 3) + 8 * (r >> 2)) * W] = acc[r];
+            for (int r = 0; r < 16; ++r) {
+                const int y = ytop + (r & 3) + 8 * (r >> 2);
+                gf[y * W] = ev[r] + od[r];
+                gf[(H - 1 - y) * W] = ev[r] - od[r];
+            }
         }
     }
+#undef S3_GLOAD
 }
 
-template <int H, int W, int YS>
+template <int H, int W>
 static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, const float* gvis,
                           const float* gflux, const float* chain_scale, int B, float out_scale,
                           float* grad, hipStream_t st) {
-    const size_t lds = (size_t)4 * 3 * 2 * (H / YS) * 16 + (size_t)(2 * F + 2) * 4;
-    step_allow_lds((const void*)k_dft_adj_s3<H, W, YS>, lds);
-    hipLaunchKernelGGL((k_dft_adj_s3<H, W, YS>), dim3(B, T, YS), dim3(S3_ADJ_THREADS), lds, st, ey_ri,
-                       ex_ri, gvis, gflux, chain_scale, grad, T, F, out_scale);
+    int cpw, gx;
+    s3_grid(B, T, &cpw, &gx);
+    const size_t lds = (size_t)24 * (H / 2) * 16;
+    step_allow_lds((const void*)k_dft_adj_s3<H, W>, lds);
+    hipLaunchKernelGGL((k_dft_adj_s3<H, W>), dim3(gx, T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
+                       gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale);
 }
 
 extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
@@ -384,12 +417,12 @@ extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, in
     STEP_REQUIRE(ey_ri && ex_ri && gvis_c64 && gflux && grad, "bh_dft_adj_sep3: null pointer");
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_adj_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
-    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3: image %dx%d not built (256, 128, 64, 32 square)", H, W);
+    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
     hipStream_t st = (hipStream_t)stream;
-    if (H == 256) launch_adj_s3<256, 256, 2>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
-    else if (H == 128) launch_adj_s3<128, 128, 1>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
-    else if (H == 64) launch_adj_s3<64, 64, 1>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
-    else launch_adj_s3<32, 32, 1>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
+    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
+    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
+
+    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3");
     return STEP_OK;
 }

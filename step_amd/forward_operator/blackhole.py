@@ -6,7 +6,7 @@ constructor kwargs, ``__call__`` / ``loss`` / ``gradient`` / ``evaluate_chisq`` 
 Three kernel paths compute the same contraction vis = A_vis x:
   * ``sep3``  -- A_vis kept as its rank-1 factors (what ehtim's ftmatrix produces), never
                  materialised; fp32 operands split exactly into three bf16 planes for the bf16
-                 matrix cores (HBM-bound).  Default for square 256 / 128 / 64 / 32 images;
+                 matrix cores (HBM-bound).  Default for square 256 / 128 / 64 images;
   * ``sep``   -- the same factors on the fp32 matrix cores (any H, W multiple of 32 up to 512);
   * ``dense`` -- an arbitrary complex A_vis tensor (``from_tensors``), packed once for MFMA.
 The set-up that the reference delegates to ehtim (array file -> uv, sigma, closure sets) is
@@ -146,9 +146,12 @@ class BlackHoleImagingTorch(Operator):
             dft = "dense"
         if sep_ok and dft != "dense":
             self._init_sep(ey, ex)
-            sep3_ok = bool(_lib.lib().bh_sep3_supported(imsize, imsize))
+            L = _lib.lib()
+            sep3_ok = bool(L.bh_sep3_supported(imsize, imsize)) and \
+                bool(L.bh_sep3_tables_ok(_lib.ptr(self._ey_ri_host), T, imsize))
             if dft == "sep3" and not sep3_ok:
-                raise ValueError("dft='sep3' is built for square 256/128/64/32 images only")
+                raise ValueError("dft='sep3' needs a square 256/128/64 image and ey tables that "
+                                 "are conjugate-symmetric about the mid-line (centred pixel grid)")
             if dft in ("auto", "sep3") and sep3_ok:
                 self.path = "sep3"
         else:
@@ -260,6 +263,7 @@ class BlackHoleImagingTorch(Operator):
         ey_ri[:, 0, F], ex_ri[:, 0, F] = 1.0, 1.0         # flux row
         ey_t = np.ascontiguousarray(ey_ri.reshape(T, 64, H).transpose(0, 2, 1))   # [T][H][64]
         self._ey_t = torch.from_numpy(ey_t).to(dev)
+        self._ey_ri_host = ey_ri
         self._ey_ri = torch.from_numpy(ey_ri).to(dev)
         self._ex_ri = torch.from_numpy(ex_ri).to(dev)
         self._A_vis = None

@@ -160,7 +160,7 @@ def sep_setup(n_sites, imsize, dev, seed=5, sigma_scale=1e-3, dft="auto", **kw):
 
 
 @pytest.mark.parametrize("n_sites,imsize,B,dft", [
-    (4, 32, 3, "sep3"), (4, 32, 3, "sep"), (8, 64, 2, "sep3"), (8, 64, 2, "sep"), (7, 96, 1, "sep"),
+    (4, 64, 3, "sep3"), (4, 32, 3, "sep"), (8, 64, 2, "sep3"), (8, 64, 2, "sep"), (7, 96, 1, "sep"),
     (5, 128, 3, "sep3")])
 def test_sep_matches_oracle(n_sites, imsize, B, dft, dev):
     """Both separable paths (3 x bf16 planes / fp32 matrix cores) against the CPU oracle; odd B
