@@ -12,6 +12,7 @@
 #include "common.h"
 
 #define CL_THREADS 256
+#define CLL_THREADS 1024     // k_closure_loss: latency-bound, one workgroup per chain
 
 struct ClosureArgs {
     bh_tables_t tab;
@@ -41,8 +42,12 @@ __device__ __forceinline__ void fold(float chi, int normalize, float& e, float& 
     else { e = chi; de = 1.0f; }
 }
 
-// LDS: sv float2[n_vis] | dcp float[n_tri] | dca float[n_quad] | red float[8]
-__global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
+// LDS: sv float2[n_vis] | dcp float[n_tri] | dca float[n_quad] | red float[32]
+//      | (STAGED) cp_ptr int[n_vis+1] | ca_ptr int[n_vis+1] | cp_ent int[3 n_tri] | ca_ent int[4 n_quad]
+// STAGED: the incidence tables of the backward gather are copied into LDS first (coalesced), so
+// the per-baseline walk ptr -> ent -> d is LDS latency instead of a chain of dependent L2 reads.
+template <bool STAGED>
+__global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     const float2* __restrict__ vis, const float* __restrict__ flux, ClosureArgs a,
     float* __restrict__ loss, float* __restrict__ chi2, float2* __restrict__ gvis,
     float* __restrict__ gflux) {
@@ -52,10 +57,29 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     float* dcp = lds + 2 * (size_t)M;
     float* dca = dcp + Kcp;
     float* red = dca + Kca;
+    const int* cp_ptr = a.tab.cp_ptr;
+    const int* ca_ptr = a.tab.ca_ptr;
+    const int* cp_ent = a.tab.cp_ent;
+    const int* ca_ent = a.tab.ca_ent;
+    if (STAGED && gvis) {
+        int* l_cp_ptr = (int*)(red + 32);
+        int* l_ca_ptr = l_cp_ptr + M + 1;
+        int* l_cp_ent = l_ca_ptr + M + 1;
+        int* l_ca_ent = l_cp_ent + 3 * Kcp;
+        if (a.w.w_cp > 0.f) {
+            for (int i = threadIdx.x; i <= M; i += CLL_THREADS) l_cp_ptr[i] = cp_ptr[i];
+            for (int i = threadIdx.x; i < 3 * Kcp; i += CLL_THREADS) l_cp_ent[i] = cp_ent[i];
+        }
+        if (a.w.w_camp > 0.f) {
+            for (int i = threadIdx.x; i <= M; i += CLL_THREADS) l_ca_ptr[i] = ca_ptr[i];
+            for (int i = threadIdx.x; i < 4 * Kca; i += CLL_THREADS) l_ca_ent[i] = ca_ent[i];
+        }
+        cp_ptr = l_cp_ptr; ca_ptr = l_ca_ptr; cp_ent = l_cp_ent; ca_ent = l_ca_ent;
+    }
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
 
-    for (int m = tid; m < M; m += CL_THREADS) sv[m] = vis[(size_t)b * M + m];
+    for (int m = tid; m < M; m += CLL_THREADS) sv[m] = vis[(size_t)b * M + m];
     __syncthreads();
 
     // --- closure phase: chi = 2 mean((1 - cos(y - phi)) / s^2), blackhole.py:472-474
@@ -63,7 +87,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     if (a.w.w_cp > 0.f) {
         const float* yv = a.y.cphase + yb * Kcp;
         const float* ys = a.y.sigma_cphase + yb * Kcp;
-        for (int k = tid; k < Kcp; k += CL_THREADS) {
+        for (int k = tid; k < Kcp; k += CLL_THREADS) {
             const float2 i1 = cdir(sv[a.tab.cp_index[3 * k + 0]], a.tab.cp_conj[3 * k + 0]);
             const float2 i2 = cdir(sv[a.tab.cp_index[3 * k + 1]], a.tab.cp_conj[3 * k + 1]);
             const float2 i3 = cdir(sv[a.tab.cp_index[3 * k + 2]], a.tab.cp_conj[3 * k + 2]);
@@ -80,7 +104,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     if (a.w.w_camp > 0.f) {
         const float* yv = a.y.logcamp + yb * Kca;
         const float* ys = a.y.sigma_logcamp + yb * Kca;
-        for (int k = tid; k < Kca; k += CL_THREADS) {
+        for (int k = tid; k < Kca; k += CLL_THREADS) {
             const float a1 = cabs(sv[a.tab.camp_index[4 * k + 0]]);
             const float a2 = cabs(sv[a.tab.camp_index[4 * k + 1]]);
             const float a3 = cabs(sv[a.tab.camp_index[4 * k + 2]]);
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     if (a.w.w_vis > 0.f) {
         const float2* yv = (const float2*)a.y.vis_c64 + yb * M;
         const float* ys = a.y.sigma_vis + yb * M;
-        for (int m = tid; m < M; m += CL_THREADS) {
+        for (int m = tid; m < M; m += CLL_THREADS) {
             const float r = cabs(make_float2(sv[m].x - yv[m].x, sv[m].y - yv[m].y)) / ys[m];
             s_vis += r * r;
         }
@@ -104,7 +128,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     if (a.w.w_amp > 0.f) {
         const float* yv = a.y.amp + yb * M;
         const float* ys = a.y.sigma_amp + yb * M;
-        for (int m = tid; m < M; m += CL_THREADS) {
+        for (int m = tid; m < M; m += CLL_THREADS) {
             const float r = (cabs(sv[m]) - yv[m]) / ys[m];
             s_amp += r * r;
         }
@@ -113,7 +137,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     float s_fl = 0.f;
     if (a.w.w_flux > 0.f) {
         const float* yv = a.y.flux + yb * T;
-        for (int t = tid; t < T; t += CL_THREADS) {
+        for (int t = tid; t < T; t += CLL_THREADS) {
             const float r = (flux[(size_t)b * T + t] - yv[t]) * 0.5f;
             s_fl += r * r;
         }
@@ -152,21 +176,21 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
     const float f_vis = a.w.w_vis * d_vis / M;          // d/dv of |v-y|^2/(2 s^2 M) = (v-y)/(s^2 M)
     const float f_amp = a.w.w_amp * d_amp * 2.0f / M;
     __syncthreads();                                     // dcp / dca complete
-    for (int m = tid; m < M; m += CL_THREADS) {
+    for (int m = tid; m < M; m += CLL_THREADS) {
         const float2 v = sv[m];
         const float n2 = v.x * v.x + v.y * v.y;
         float gp = 0.f, gl = 0.f;                        // coefficients of i v/|v|^2 and v/|v|^2
         if (a.w.w_cp > 0.f) {
-            for (int e = a.tab.cp_ptr[m]; e < a.tab.cp_ptr[m + 1]; ++e) {
-                const int ent = a.tab.cp_ent[e];
+            for (int e = cp_ptr[m]; e < cp_ptr[m + 1]; ++e) {
+                const int ent = cp_ent[e];
                 const float d = dcp[ent >> 3];
                 gp += (ent & 1) ? -d : d;                // conj leg: arg(conj v) = -arg v
             }
             gp *= f_cp;
         }
         if (a.w.w_camp > 0.f) {
-            for (int e = a.tab.ca_ptr[m]; e < a.tab.ca_ptr[m + 1]; ++e) {
-                const int ent = a.tab.ca_ent[e];
+            for (int e = ca_ptr[m]; e < ca_ptr[m + 1]; ++e) {
+                const int ent = ca_ent[e];
                 const float d = dca[ent >> 3];
                 gl += (((ent >> 1) & 3) < 2) ? d : -d;   // legs 0,1 numerator, 2,3 denominator
             }
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_loss(
         }
         gvis[(size_t)b * M + m] = make_float2(gx, gy);
     }
-    for (int t = tid; t < T; t += CL_THREADS) {
+    for (int t = tid; t < T; t += CLL_THREADS) {
         float g = 0.f;
         if (a.w.w_flux > 0.f)
             g = a.w.w_flux * (flux[(size_t)b * T + t] - (a.y.flux + yb * T)[t]) * 0.5f / T;
@@ -206,7 +230,7 @@ static int check_tables(const char* who, const bh_tables_t* tab) {
                  "%s: bad table sizes", who);
     STEP_REQUIRE(tab->n_tri == 0 || (tab->cp_index && tab->cp_conj), "%s: null cp tables", who);
     STEP_REQUIRE(tab->n_quad == 0 || tab->camp_index, "%s: null camp tables", who);
-    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 16) * sizeof(float);
+    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 32) * sizeof(float);
     STEP_REQUIRE(lds <= 150 * 1024, "%s: tables need %zu B of LDS (max 150 KiB)", who, lds);
     return STEP_OK;
 }
@@ -228,10 +252,18 @@ extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
                                (!(w->w_camp > 0) || (tab->ca_ptr && tab->ca_ent))),
                  "bh_closure_loss: incidence tables missing");
     ClosureArgs a{*tab, *y, *w};
-    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 16) * sizeof(float);
-    step_allow_lds((const void*)k_closure_loss, lds);
-    hipLaunchKernelGGL(k_closure_loss, dim3(B), dim3(CL_THREADS), lds, (hipStream_t)stream,
-                       (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
+    const size_t base = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 32) * sizeof(float);
+    const size_t staged = base + (2 * ((size_t)tab->n_vis + 1) + 3 * (size_t)tab->n_tri +
+                                  4 * (size_t)tab->n_quad) * sizeof(int);
+    if (staged <= 150 * 1024) {
+        step_allow_lds((const void*)k_closure_loss<true>, staged);
+        hipLaunchKernelGGL(k_closure_loss<true>, dim3(B), dim3(CLL_THREADS), staged, (hipStream_t)stream,
+                           (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
+    } else {
+        step_allow_lds((const void*)k_closure_loss<false>, base);
+        hipLaunchKernelGGL(k_closure_loss<false>, dim3(B), dim3(CLL_THREADS), base, (hipStream_t)stream,
+                           (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
+    }
     STEP_CHECK_LAUNCH("bh_closure_loss");
     return STEP_OK;
 }

@@ -50,6 +50,17 @@ def test_host_entry_points_reject_bad_arguments():
     # GPU entry points validate shapes before touching the device
     assert L.bh_dft_fwd_sep(None, None, 64, 28, 256, 256, None, 1, 1.0, 0.0, 0.0, None, None, None) != 0
     assert L.mri_forward(None, 1, 12, 192, None, None, 1, 52, None, None) != 0
+    assert L.bh_dft_fwd_sep3(None, None, 64, 28, 256, 256, None, 1, 1.0, 0.0, 0.0, None, None, None) != 0
+    assert [L.bh_sep3_supported(n, n) for n in (32, 64, 96, 128, 256, 512)] == [0, 1, 0, 1, 1, 0]
+    assert L.bh_sep3_supported(256, 128) == 0
+    # fold precondition: Re ey even / Im ey odd about the mid-line, bit for bit (host check)
+    y = (np.arange(8) - 3.5)[None, None, None, :] * np.linspace(0.1, 0.9, 32)[None, None, :, None]
+    ey = np.concatenate([np.cos(y), np.sin(y)], axis=1).astype(np.float32)      # [1][2][32][8]
+    ey = np.ascontiguousarray(np.repeat(ey, 2, axis=0))
+    assert L.bh_sep3_tables_ok(_lib.ptr(ey), 2, 8) == 1
+    ey[1, 1, 4, 6] = np.nextafter(ey[1, 1, 4, 6], np.float32(9))
+    assert L.bh_sep3_tables_ok(_lib.ptr(ey), 2, 8) == 0
+    assert L.bh_sep3_tables_ok(None, 2, 8) == 0
     assert L.bh_dense_rows_padded(28) == 64 and L.bh_dense_rows_padded(6) == 32
     assert L.bh_dense_packed_floats(64, 28, 65536) == 64 * 64 * 65536
 

@@ -183,6 +183,52 @@ def test_sep_matches_oracle(n_sites, imsize, B, dft, dev):
     g_got, l_got = op.gradient(x.to(dev), y, return_loss=True)
     assert_close(l_got, l_ref, RTOL, "sep loss")
     assert_close(g_got, g_ref, RTOL, "sep gradient")
+    # evaluator: the clip(min=0) variant of the forward kernel + per-frame flux alignment
+    ev, ev_ref = op.evaluate_chisq(x.to(dev), y), orc.evaluate_chisq(x, yo)
+    for k in ev_ref:
+        assert_close(ev[k], ev_ref[k], RTOL, "sep evaluate_chisq " + k)
+
+
+def test_sep3_needs_mirror_symmetric_tables(dev):
+    """The folded kernels are only valid for ey[f][H-1-y] == conj(ey[f][y]); the operator checks
+    the tables (bh_sep3_tables_ok) and falls back to the fp32 separable path otherwise."""
+    from step_amd import _lib, eht_lite
+    from step_amd.forward_operator import BlackHoleImagingTorch
+    tab = eht_lite.synthetic_table(4, 64, seed=5, sigma_scale=1e-3)
+    op = BlackHoleImagingTorch(imsize=64, ref_multiplier=0.001, device=dev, obs_table=tab)
+    assert op.path == "sep3"
+    good = np.ascontiguousarray(op._ey_ri_host)
+    assert _lib.lib().bh_sep3_tables_ok(_lib.ptr(good), 64, 64) == 1
+    bad = good.copy()
+    bad[3, 1, 2, 5] += 1e-3                                   # Im ey no longer odd
+    assert _lib.lib().bh_sep3_tables_ok(_lib.ptr(bad), 64, 64) == 0
+    # unsupported shape -> error code, nothing launched
+    rc = _lib.lib().bh_dft_fwd_sep3(op._ey_t.data_ptr(), op._ex_ri.data_ptr(), 64, op.F, 96, 96,
+                                    op._ey_t.data_ptr(), 1, 1.0, 0.0, 0.0, op._ey_t.data_ptr(),
+                                    op._ey_t.data_ptr(), None)
+    assert rc != 0 and b"not built" in _lib.lib().step_last_error()
+
+
+def test_sep3_nan_and_batch_sizes(dev):
+    """NaN pixels stay NaN through the operand split; every chain count (odd, prime, > CUs/T
+    groups) gives the same per-chain result as batch 1 (persistent workgroups walk chains)."""
+    op, _, _ = sep_setup(5, 64, dev, dft="sep3")
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.rand(13, 64, 1, 64, 64, device=dev, generator=gen)
+    v = op.forward_vis(x)
+    for b in (0, 6, 12):
+        assert torch.equal(v[b:b + 1], op.forward_vis(x[b:b + 1]))
+    gv = torch.randn(13, 64 * op.F, 2, device=dev, generator=gen)
+    gf = torch.randn(13, 64, device=dev, generator=gen)
+    g = op._adjoint(gv, gf, None, 1.0)
+    for b in (0, 7, 12):
+        assert torch.equal(g[b:b + 1], op._adjoint(gv[b:b + 1], gf[b:b + 1], None, 1.0))
+    xn = x[:2].clone()
+    xn[1, 10, 0, 3, 7] = float("nan")
+    vn = op.forward_vis(xn)
+    assert torch.isfinite(torch.view_as_real(vn[0])).all()
+    assert torch.isnan(torch.view_as_real(vn[1]).view(64, -1)[10]).all()
+    assert torch.isfinite(torch.view_as_real(vn[1]).view(64, -1)[11]).all()
 
 
 def test_sep_equals_dense_path(dev):
