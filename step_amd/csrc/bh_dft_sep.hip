@@ -40,7 +40,7 @@ __device__ __forceinline__ void fwd_strip(const float* __restrict__ xf, const fl
     float xa[SEP_U], xb[SEP_U];
 #define SEP_LOAD(dst, blk)                                                         \
     _Pragma("unroll") for (int u = 0; u < SEP_U; ++u)                              \
-        dst[u] = xf[xo + (2 * ((blk) * SEP_U + u)) * W];
+        dst[u] = __builtin_nontemporal_load(xf + xo + (2 * ((blk) * SEP_U + u)) * W);
 #ifdef EXP_FWD_NOFLUSH
 #define SEP_FLUSH tot0 = acc0; tot1 = acc1;
 #define SEP_ACCINIT acc0 = tot0; acc1 = tot1;
