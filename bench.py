@@ -186,6 +186,11 @@ def main():
                             traffic=measured_traffic("k_" + dom + "_s3", B == 64),
                             algorithmic="4*T*H*W bytes per chain per direction x %d chains" % B,
                             kernels_ms=kern,
+                            # SURVEY 8d prices the DFT in fp32 flops against the fp32 matrix peak:
+                            # the same launch in that currency (the kernel does not use that pipe)
+                            fp32_mfma_view=dict(achieved=per[dom]["tflops"], peak=FP32_MATRIX_PEAK_TFLOPS,
+                                                unit="TFLOP/s", frac=per[dom]["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+                                                algorithmic="4*T*F*H*W flop per chain per direction"),
                             fp32_equivalent_tflops={k: v["tflops"] for k, v in per.items()},
                             other_gbs={k: byts / (v["ms"] * 1e-3) / 1e9 for k, v in per.items() if k != dom})
             else:
