@@ -17,6 +17,16 @@
 #include "common.h"
 #include "fft_small.h"
 
+#ifdef EXP_MRI_TIMING   // experiment builds only: phase timestamps of workgroup 0
+__device__ unsigned long long g_mri_t[16];
+#define MRI_TICK(i) { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_mri_t[i] = wall_clock64(); }
+extern "C" int mri_debug_timing(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mri_t), sizeof(unsigned long long) * 16);
+}
+#else
+#define MRI_TICK(i)
+#endif
+
 #define MRI_R 192
 #define MRI_THREADS 512
 #define MRI_SW 32                 // strip width (columns)
@@ -175,33 +185,61 @@ __device__ __forceinline__ void rows_fft_x(const MriLds& L, int nk) {
     __syncthreads();
 }
 
-// Steps 1-2 for kept rows [g0, g0+nk): leaves Rk[j][kx] = (-1)^ky * FFT2(z)[ky][kx], ky = rowlist[g0+j]
-__device__ __forceinline__ void forward_rows(const MriLds& L, const float* __restrict__ xr,
-                                             const float* __restrict__ xi,
-                                             const int* __restrict__ rowlist, int g0, int nk) {
-    const int tid = threadIdx.x;
-    constexpr int NP = MRI_R * MRI_SW / MRI_THREADS;      // 12 elements of a strip per thread
-    const int col = tid & 31, row0 = tid >> 5;             // element i: row = row0 + 16 i
-    // the next strip's pixels travel to registers while the current strip is transformed
-    cf32 pre[NP];
+constexpr int MRI_NP = MRI_R * MRI_SW / MRI_THREADS;      // 12 elements of a strip per thread
+constexpr int MRI_YQ = 6;   // float4 loads per thread and strip for the masked-out rows (<= 192 rows)
+
+// pixels of strip `strip` owned by this thread: element i is row (tid >> 5) + 16 i, column tid & 31
+__device__ __forceinline__ void load_strip(const float* __restrict__ xr, const float* __restrict__ xi,
+                                           int strip, cf32 (&pre)[MRI_NP]) {
+    const int col = threadIdx.x & 31, row0 = threadIdx.x >> 5;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int g = (row0 + 16 * i) * MRI_R + col;
+    for (int i = 0; i < MRI_NP; ++i) {
+        const int g = (row0 + 16 * i) * MRI_R + strip * MRI_SW + col;
         pre[i] = c_make(xr[g], xi[g]);
     }
-    for (int strip = 0; strip < MRI_R / MRI_SW; ++strip) {
+}
+
+// Steps 1-2 for kept rows [g0, g0+nk): leaves Rk[j][kx] = (-1)^ky * FFT2(z)[ky][kx], ky = rowlist[g0+j].
+// `pre` holds strip 0 on entry (loaded by the caller ahead of the table set-up).
+// y != nullptr (loss kernels, first row group): the |y|^2 of the masked-out rows -- where A(x) = 0,
+// so the residual is -y -- is summed along the way: each strip every thread loads its share of a
+// sixth of those rows as float4 before the strip's FFT and adds it up after, so the L2 latency
+// hides behind the transform.
+__device__ __forceinline__ void forward_rows(const MriLds& L, const float* __restrict__ xr,
+                                             const float* __restrict__ xi, int g0, int nk,
+                                             cf32 (&pre)[MRI_NP], const float* __restrict__ y,
+                                             int n_un, float& acc) {
+    const int tid = threadIdx.x;
+    constexpr int NP = MRI_NP, NS = MRI_R / MRI_SW, Q = MRI_R / 4;   // Q float4 per row
+    const int col = tid & 31, row0 = tid >> 5;             // element i: row = row0 + 16 i
+    for (int strip = 0; strip < NS; ++strip) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) L.S[(row0 + 16 * i) * MRI_SW + col] = pre[i];
         __syncthreads();
-        if (strip + 1 < MRI_R / MRI_SW) {
+        // the next strip's pixels travel to registers while the current strip is transformed
+        if (strip + 1 < NS) load_strip(xr, xi, strip + 1, pre);
+        float4 yq[MRI_YQ];
+        const int q0 = strip * n_un / NS;
+        const int total = y ? ((strip + 1) * n_un / NS - q0) * (2 * Q) : 0;   // both planes
+        if (total > 0) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                const int g = (row0 + 16 * i) * MRI_R + (strip + 1) * MRI_SW + col;
-                pre[i] = c_make(xr[g], xi[g]);
+            for (int i = 0; i < MRI_YQ; ++i) {
+                const int e = min(tid + i * MRI_THREADS, total - 1);
+                const int q = e / (2 * Q), r = e - q * (2 * Q);               // r: plane * Q + c
+                const int pl = r >= Q;
+                yq[i] = *(const float4*)(y + (size_t)pl * MRI_R * MRI_R + L.unrow[q0 + q] * MRI_R +
+                                         4 * (r - pl * Q));
             }
         }
         strip_fft_fwd(L, strip, g0, nk);
+        if (total > 0) {
+#pragma unroll
+            for (int i = 0; i < MRI_YQ; ++i)
+                if (tid + i * MRI_THREADS < total)
+                    acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
+        }
     }
+    MRI_TICK(3)
     rows_fft_x<-1>(L, nk);
 }
 
@@ -244,12 +282,16 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
     const float* xi = xr + MRI_R * MRI_R;
     float* outr = out + (size_t)frame * 2 * MRI_R * MRI_R;
     float* outi = outr + MRI_R * MRI_R;
+    cf32 pre[MRI_NP];
+    load_strip(xr, xi, 0, pre);                        // in flight during the table set-up
     load_tables(L, rowlist, nk_total);
     for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS)
         if (L.rowpos[e / MRI_R] < 0) { outr[e] = 0.f; outi[e] = 0.f; }
+    float unused = 0.f;
     for (int g0 = 0; g0 < nk_total; g0 += nkc) {
         const int nk = min(nkc, nk_total - g0);
-        forward_rows(L, xr, xi, rowlist, g0, nk);
+        if (g0) load_strip(xr, xi, 0, pre);
+        forward_rows(L, xr, xi, g0, nk, pre, nullptr, 0, unused);
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
             const int j = e / MRI_R, kx = e - j * MRI_R;
             const int ky = L.rowl[g0 + j];
@@ -267,6 +309,7 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
 __device__ __forceinline__ void adjoint_rows(const MriLds& L, const int* __restrict__ rowlist,
                                              int g0, int nk, float* __restrict__ dst) {
     rows_fft_x<1>(L, nk);
+    MRI_TICK(6)
     for (int strip = 0; strip < MRI_R / MRI_SW; ++strip)
         strip_fft_inv(L, strip, g0, nk, dst, dst + MRI_R * MRI_R, g0 != 0);
 }
@@ -288,12 +331,16 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
     const float* yr = y + ((size_t)(y_batch > 1 ? b : 0) * T + t) * fsz;
     const float* yi = yr + MRI_R * MRI_R;
     const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
+    MRI_TICK(0)
+    cf32 pre[MRI_NP];
+    load_strip(xr, xi, 0, pre);                        // in flight during the table set-up
     load_tables(L, rowlist, nk_total);
+    MRI_TICK(1)
 
-    // rows outside the mask: A(x) = 0 there, the residual is -y (constant in x)
+    // rows outside the mask are summed inside forward_rows; a frame with no kept row does it here
     float acc = 0.f;
-    {
-        const int total = (MRI_R - nk_total) * MRI_R;       // branch-free so the loads batch
+    if (nk_total == 0) {
+        const int total = MRI_R * MRI_R;
 #pragma unroll 8
         for (int e = tid; e < total; e += MRI_THREADS) {
             const int q = e / MRI_R;
@@ -309,7 +356,9 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
     }
     for (int g0 = 0; g0 < nk_total; g0 += nkc) {
         const int nk = min(nkc, nk_total - g0);
-        forward_rows(L, xr, xi, rowlist, g0, nk);
+        if (g0) load_strip(xr, xi, 0, pre);
+        forward_rows(L, xr, xi, g0, nk, pre, g0 == 0 ? yr : nullptr, MRI_R - nk_total, acc);
+        MRI_TICK(4)
         // residual, loss, adjoint input 2 * (-1)^(ky+kx) * r  (the row sign is already in Rk)
 #pragma unroll 4
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
@@ -325,7 +374,9 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
             L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
         }
         __syncthreads();
+        MRI_TICK(5)
         if (grad) adjoint_rows(L, rowlist, g0, nk, grad + (size_t)frame * fsz);
+        MRI_TICK(7)
     }
     const float tot = block_sum(acc, L.red);
     if (tid == 0) loss_part[frame] = tot;
