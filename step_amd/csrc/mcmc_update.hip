@@ -9,6 +9,23 @@
 // scalars; here they arrive already rounded to fp32 in mcmc_params_t.
 #include "common.h"
 
+// One element of the update; `v_old` is only read when momentum != 0 (the shipped blackhole
+// configuration runs hmc with momentum 0, where the old velocity has weight zero).
+__device__ __forceinline__ float mcmc_elem(float xi, float g, float xti, float pr, float e, float v_old,
+                                           const mcmc_params_t& p, float& v_new) {
+    const float s = -g * p.inv_tau2 + (xti - xi) * p.inv_sigma2 + pr;
+    if (p.algo == 0) {
+        v_new = 0.f;
+        return xi + p.lr * s + p.sqrt_2lr * e;
+    }
+    v_new = p.momentum * v_old + p.sqrt_lr * s + p.noise_scale * e;
+    return xi + v_new * p.sqrt_lr;
+}
+
+// VEC = 4: every pointer 16-byte aligned and n % 4 == 0 (float4 accesses); VEC = 1 otherwise.
+// grad / prior / eps are read once and never again: non-temporal, so that x and the velocity
+// (read and written) keep the cache.
+template <int VEC>
 __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, float* __restrict__ vel,
                                                      const float* __restrict__ grad,
                                                      const float* __restrict__ xt,
@@ -16,21 +33,38 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
                                                      const float* __restrict__ eps, int64_t n,
                                                      mcmc_params_t p, int32_t* __restrict__ nan_flag) {
     bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const float xi = x[i];
-        float s = -grad[i] * p.inv_tau2 + (xt[i] - xi) * p.inv_sigma2;
-        if (prior) s += prior[i];
-        float xn;
-        if (p.algo == 0) {
-            xn = xi + p.lr * s + p.sqrt_2lr * eps[i];
-        } else {
-            const float v = p.momentum * vel[i] + p.sqrt_lr * s + p.noise_scale * eps[i];
-            vel[i] = v;
-            xn = xi + v * p.sqrt_lr;
+    const bool rd_vel = p.algo == 1 && p.momentum != 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const f4 xi = ((const f4*)x)[i];
+            const f4 g = __builtin_nontemporal_load((const f4*)grad + i);
+            const f4 e = __builtin_nontemporal_load((const f4*)eps + i);
+            const f4 xti = ((const f4*)xt)[i];
+            f4 pr = {0.f, 0.f, 0.f, 0.f}, vo = {0.f, 0.f, 0.f, 0.f}, xn, vn;
+            if (prior) pr = __builtin_nontemporal_load((const f4*)prior + i);
+            if (rd_vel) vo = ((const f4*)vel)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v;
+                xn[k] = mcmc_elem(xi[k], g[k], xti[k], pr[k], e[k], vo[k], p, v);
+                vn[k] = v;
+                bad |= (xn[k] != xn[k]);
+            }
+            ((f4*)x)[i] = xn;
+            if (p.algo == 1) ((f4*)vel)[i] = vn;
         }
-        x[i] = xn;
-        bad |= (xn != xn);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float v;
+            const float xn = mcmc_elem(x[i], grad[i], xt[i], prior ? prior[i] : 0.f, eps[i],
+                                       rd_vel ? vel[i] : 0.f, p, v);
+            if (p.algo == 1) vel[i] = v;
+            x[i] = xn;
+            bad |= (xn != xn);
+        }
     }
     if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
 }
@@ -42,10 +76,17 @@ extern "C" int mcmc_update(float* x, float* velocity, const float* grad, const f
     STEP_REQUIRE(n > 0, "mcmc_update: n = %lld", (long long)n);
     STEP_REQUIRE(p->algo == 0 || p->algo == 1, "mcmc_update: unknown algo %d", p->algo);
     STEP_REQUIRE(p->algo == 0 || velocity, "mcmc_update: hmc needs a velocity buffer");
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_mcmc_update, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                       velocity, grad, xt, prior, eps, n, *p, nan_flag);
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
+                         (uintptr_t)prior | (uintptr_t)eps;
+    const bool vec = (n % 4 == 0) && (al % 16 == 0);
+    int64_t blocks = ((vec ? n / 4 : n) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (vec)
+        hipLaunchKernelGGL(k_mcmc_update<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag);
+    else
+        hipLaunchKernelGGL(k_mcmc_update<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag);
     STEP_CHECK_LAUNCH("mcmc_update");
     return STEP_OK;
 }
