@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["init_distributed", "shard_items", "chain_generator", "gather_to_rank0",
-           "sample_posterior"]
+           "sample_posterior", "write_sample_dir"]
 
 
 def init_distributed(backend=None):
@@ -98,3 +98,23 @@ def sample_posterior(sampler, model, operator, measurement, num_samples, seed=37
     else:                      # more ranks than chains: this rank contributes an empty shard
         local = torch.empty((0,) + tuple(model.get_data_shape()), device=device)
     return gather_to_rank0(local, ids, num_samples, group)
+
+
+def write_sample_dir(idx_dir, observations, samples, videos=None):
+    """On-disk layout of the reference's loop (sample.py:59-67) for one test video: ``observations.pth``
+    (the measurement container, under the reference's pickle identity when it is a black-hole
+    observation), ``videos.pth`` (ground truth, optional) and one ``sample_{i}.pth`` per posterior
+    sample, each ``[1, *video_shape]`` on the CPU as the reference writes them.  Rank 0 only."""
+    from pathlib import Path
+
+    from .forward_operator.blackhole import BlackHoleObservation, save_observation
+    idx_dir = Path(idx_dir)
+    idx_dir.mkdir(parents=True, exist_ok=True)
+    if isinstance(observations, BlackHoleObservation):
+        save_observation(observations, idx_dir / "observations.pth")
+    else:
+        torch.save(observations.to("cpu"), idx_dir / "observations.pth")
+    if videos is not None:
+        torch.save(videos.to("cpu"), idx_dir / "videos.pth")
+    for i in range(samples.shape[0]):
+        torch.save(samples[i:i + 1].to("cpu").clone(), idx_dir / ("sample_%d.pth" % i))

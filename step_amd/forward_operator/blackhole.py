@@ -21,7 +21,7 @@ import torch
 from .. import _lib, eht_lite
 from .base import Operator, register_operator
 
-__all__ = ["BlackHoleObservation", "BlackHoleImagingTorch"]
+__all__ = ["BlackHoleObservation", "BlackHoleImagingTorch", "save_observation", "load_observation"]
 
 _NEG_INF = float("-inf")
 
@@ -74,6 +74,50 @@ class BlackHoleObservation(object):
     @classmethod
     def merge(cls, obs_list):
         return cls(**{k: torch.cat([getattr(o, k) for o in obs_list], dim=0) for k in cls.FIELDS})
+
+
+class _RefObservation(BlackHoleObservation):
+    """The same container under the reference's pickle identity
+    (``forward_operator.blackhole.BlackHoleObservation``, what ``sample.py:62`` writes to
+    ``observations.pth``): instance state is the nine tensors under the reference's attribute names."""
+
+
+_RefObservation.__module__ = "forward_operator.blackhole"
+_RefObservation.__qualname__ = _RefObservation.__name__ = "BlackHoleObservation"
+
+
+def save_observation(obs, path):
+    """Write ``obs`` the way the reference does (``torch.save(observations.to('cpu'), ...)``,
+    sample.py:62) so that the reference's ``torch.load`` returns its own class."""
+    import sys
+    import types
+    name = "forward_operator.blackhole"
+    ref_mod = sys.modules.get(name)
+    if ref_mod is not None and hasattr(ref_mod, "BlackHoleObservation"):
+        torch.save(ref_mod.BlackHoleObservation(*obs.to("cpu").to_list()), path)   # inside the reference
+        return
+    added = []
+    try:
+        for m in ("forward_operator", name):
+            if m not in sys.modules:
+                sys.modules[m] = types.ModuleType(m)
+                added.append(m)
+        sys.modules[name].BlackHoleObservation = _RefObservation
+        torch.save(_RefObservation(*obs.to("cpu").to_list()), path)
+    finally:
+        for m in added:
+            sys.modules.pop(m, None)
+
+
+def load_observation(path, map_location="cpu"):
+    """Read an ``observations.pth`` written by the reference or by ``save_observation`` with
+    torch's weights-only unpickler: the only non-tensor global it may resolve is the
+    observation container, so nothing from the file is executed."""
+    with torch.serialization.safe_globals([_RefObservation]):
+        o = torch.load(path, map_location=map_location, weights_only=True)
+    if not isinstance(o, BlackHoleObservation):
+        raise TypeError("%s does not hold a BlackHoleObservation (got %s)" % (path, type(o).__name__))
+    return BlackHoleObservation(*o.to_list())
 
 
 def _f32(t, device):

@@ -84,3 +84,68 @@ def test_trajectory_recorder_and_daps_construction():
     s.batch_consistency = True
     n = s.get_randn_like(ref)
     assert torch.equal(n[:, 0], n[:, 4])
+
+
+def test_observation_pickle_roundtrip_with_reference_identity(tmp_path):
+    """observations.pth compatibility (reference sample.py:62): files carry the reference's class
+    identity and load through torch's weights-only unpickler; a file written by a class that only
+    looks like the reference's (same module path, same attribute names) loads too."""
+    import pickle
+    import sys
+    import types
+    import torch
+    from step_amd.forward_operator.blackhole import (BlackHoleObservation, load_observation,
+                                                     save_observation)
+    g = torch.Generator().manual_seed(0)
+    fields = [torch.randn(2, 5, generator=g) for _ in range(9)]
+    fields[0] = torch.complex(fields[0], fields[1])
+    obs = BlackHoleObservation(*fields)
+    path = tmp_path / "observations.pth"
+    save_observation(obs, path)
+    assert "forward_operator.blackhole" not in sys.modules          # the temporary stub is gone
+    raw = open(path, "rb").read()
+    assert b"forward_operator.blackhole" in raw and b"step_amd" not in raw
+    back = load_observation(path)
+    assert type(back) is BlackHoleObservation
+    for a, b in zip(obs.to_list(), back.to_list()):
+        assert torch.equal(a, b)
+
+    # a stand-in for the reference's module, written with plain torch.save as sample.py does
+    mod = types.ModuleType("forward_operator.blackhole")
+
+    class BlackHoleObservation2(object):
+        def __init__(self, *f):
+            (self.vis, self.sigma_vis, self.amp, self.sigma_amp, self.cphase, self.sigma_cphase,
+             self.logcamp, self.sigma_logcamp, self.flux) = f
+    BlackHoleObservation2.__module__ = "forward_operator.blackhole"
+    BlackHoleObservation2.__qualname__ = BlackHoleObservation2.__name__ = "BlackHoleObservation"
+    mod.BlackHoleObservation = BlackHoleObservation2
+    sys.modules["forward_operator"] = types.ModuleType("forward_operator")
+    sys.modules["forward_operator.blackhole"] = mod
+    try:
+        torch.save(BlackHoleObservation2(*fields), tmp_path / "ref.pth")
+        save_observation(obs, tmp_path / "ours_inside_ref.pth")     # uses the loaded module's class
+    finally:
+        del sys.modules["forward_operator.blackhole"], sys.modules["forward_operator"]
+    for name in ("ref.pth", "ours_inside_ref.pth"):
+        back = load_observation(tmp_path / name)
+        for a, b in zip(fields, back.to_list()):
+            assert torch.equal(a, b)
+    # anything else in the file is refused by the weights-only loader
+    with open(tmp_path / "evil.pth", "wb") as fh:
+        pickle.dump(types.SimpleNamespace(a=1), fh)
+    with pytest.raises(Exception):
+        load_observation(tmp_path / "evil.pth")
+
+
+def test_write_sample_dir_layout(tmp_path):
+    import torch
+    from step_amd.driver import write_sample_dir
+    from step_amd.forward_operator.blackhole import BlackHoleObservation, load_observation
+    obs = BlackHoleObservation(*[torch.full((1, 3), float(i)) for i in range(9)])
+    samples = torch.arange(24.0).view(3, 2, 1, 2, 2)
+    write_sample_dir(tmp_path / "0007", obs, samples, videos=samples[:1])
+    names = sorted(p.name for p in (tmp_path / "0007").iterdir())
+    assert names == ["observations.pth", "sample_0.pth", "sample_1.pth", "sample_2.pth", "videos.pth"]
+    assert torch.equal(torch.load(tmp_path / "0007" / "sample_2.pth", weights_only=True), samples[2:3])
+    assert torch.equal(load_observation(tmp_path / "0007" / "observations.pth").flux, obs.flux)
