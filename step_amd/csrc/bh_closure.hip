@@ -42,7 +42,7 @@ __device__ __forceinline__ void fold(float chi, int normalize, float& e, float& 
     else { e = chi; de = 1.0f; }
 }
 
-// LDS: sv float2[n_vis] | dcp float[n_tri] | dca float[n_quad] | red float[32]
+// LDS: sv float2[n_vis] | dcp float[n_tri] | dca float[n_quad] | red float[96]
 //      | (STAGED) cp_ptr int[n_vis+1] | ca_ptr int[n_vis+1] | cp_ent int[3 n_tri] | ca_ent int[4 n_quad]
 // STAGED: the incidence tables of the backward gather are copied into LDS first (coalesced), so
 // the per-baseline walk ptr -> ent -> d is LDS latency instead of a chain of dependent L2 reads.
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     const int* cp_ent = a.tab.cp_ent;
     const int* ca_ent = a.tab.ca_ent;
     if (STAGED && gvis) {
-        int* l_cp_ptr = (int*)(red + 32);
+        int* l_cp_ptr = (int*)(red + 96);
         int* l_ca_ptr = l_cp_ptr + M + 1;
         int* l_cp_ent = l_ca_ptr + M + 1;
         int* l_ca_ent = l_cp_ent + 3 * Kcp;
@@ -142,11 +142,28 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
             s_fl += r * r;
         }
     }
-    const float chi_cp = a.w.w_cp > 0.f ? 2.0f * block_sum(s_cp, red) / Kcp : 0.f;
-    const float chi_ca = a.w.w_camp > 0.f ? block_sum(s_ca, red) / Kca : 0.f;
-    const float chi_vis = a.w.w_vis > 0.f ? block_sum(s_vis, red) / M * 0.5f : 0.f;
-    const float chi_amp = a.w.w_amp > 0.f ? block_sum(s_amp, red) / M : 0.f;
-    const float chi_fl = a.w.w_flux > 0.f ? block_sum(s_fl, red) / T : 0.f;
+    // the five partial sums in one pass: wave sums, one LDS exchange, every thread adds the
+    // per-wave values in wave order (two barriers instead of ten)
+    float tot[5] = {wave_sum(s_cp), wave_sum(s_ca), wave_sum(s_vis), wave_sum(s_amp), wave_sum(s_fl)};
+    {
+        const int w = tid >> 6, nw = CLL_THREADS >> 6;
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) red[q * nw + w] = tot[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            float t = 0.f;
+            for (int i = 0; i < nw; ++i) t += red[q * nw + i];
+            tot[q] = t;
+        }
+    }
+    const float chi_cp = a.w.w_cp > 0.f ? 2.0f * tot[0] / Kcp : 0.f;
+    const float chi_ca = a.w.w_camp > 0.f ? tot[1] / Kca : 0.f;
+    const float chi_vis = a.w.w_vis > 0.f ? tot[2] / M * 0.5f : 0.f;
+    const float chi_amp = a.w.w_amp > 0.f ? tot[3] / M : 0.f;
+    const float chi_fl = a.w.w_flux > 0.f ? tot[4] / T : 0.f;
 
     float e_cp = 0.f, d_cp = 0.f, e_ca = 0.f, d_ca = 0.f, e_vis = 0.f, d_vis = 0.f, e_amp = 0.f,
           d_amp = 0.f;
@@ -230,7 +247,7 @@ static int check_tables(const char* who, const bh_tables_t* tab) {
                  "%s: bad table sizes", who);
     STEP_REQUIRE(tab->n_tri == 0 || (tab->cp_index && tab->cp_conj), "%s: null cp tables", who);
     STEP_REQUIRE(tab->n_quad == 0 || tab->camp_index, "%s: null camp tables", who);
-    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 32) * sizeof(float);
+    const size_t lds = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 96) * sizeof(float);
     STEP_REQUIRE(lds <= 150 * 1024, "%s: tables need %zu B of LDS (max 150 KiB)", who, lds);
     return STEP_OK;
 }
@@ -252,7 +269,7 @@ extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
                                (!(w->w_camp > 0) || (tab->ca_ptr && tab->ca_ent))),
                  "bh_closure_loss: incidence tables missing");
     ClosureArgs a{*tab, *y, *w};
-    const size_t base = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 32) * sizeof(float);
+    const size_t base = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 96) * sizeof(float);
     const size_t staged = base + (2 * ((size_t)tab->n_vis + 1) + 3 * (size_t)tab->n_tri +
                                   4 * (size_t)tab->n_quad) * sizeof(int);
     if (staged <= 150 * 1024) {
