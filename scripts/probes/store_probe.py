@@ -1,0 +1,17 @@
+import torch, ctypes as C
+L = C.CDLL('variants/store_probe.so')
+B = 64
+out = torch.empty(B, 64, 256, 256, device='cuda:0')
+st = torch.cuda.current_stream().cuda_stream
+def t(fn, n=300):
+    for _ in range(100): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+gb = out.numel() * 4 / 1e9
+for mode, name in ((0, 'adjoint pattern (2 x 128 B per instr)'), (1, 'rows as float4 (1 KB per instr)'), (2, 'rows as dword (256 B per instr)')):
+    m = t(lambda: L.store_probe(mode, C.c_void_p(out.data_ptr()), B, C.c_void_p(st)))
+    print('%-40s %.3f ms  %.0f GB/s' % (name, m, gb / m * 1e3))
+m = t(lambda: out.fill_(1.0)); print('%-40s %.3f ms  %.0f GB/s' % ('torch fill_', m, gb / m * 1e3))
