@@ -120,6 +120,44 @@ def load_observation(path, map_location="cpu"):
     return BlackHoleObservation(*o.to_list())
 
 
+def factor_A_vis(A, H, W, tol=1e-6):
+    """Rank-1 factors of a dense DFT matrix: ``A[t,f].reshape(H,W) = outer(ey[t,f], ex[t,f])``.
+
+    ehtim's ftmatrix rows are separable (pulse * e^{2 pi i y v} * e^{2 pi i x u}),
+    but the reference only keeps the product, rounded to complex64.  Per row: pivot on the largest
+    entry, ``ex = A[yc, :]``, ``ey = A[:, xc] / A[yc, xc]`` (fp64), and accept only if the outer
+    product reproduces every entry to ``tol`` of the row's largest magnitude (a few fp32 ulps: the
+    entries were rounded separately).  The free complex constant between the two factors is then
+    chosen so that ``ey[H-1-y] = conj(ey[y])`` when the grid allows it (centred pixel grid), and the
+    remaining asymmetry -- rounding only, below ``tol`` -- is averaged out, which is what lets the
+    folded kernels run.  Returns ``(ey [T,F,H], ex [T,F,W])`` complex128 or None."""
+    T, F, HW = A.shape
+    ey = np.empty((T, F, H), np.complex128)
+    ex = np.empty((T, F, W), np.complex128)
+    for t in range(T):
+        At = A[t].detach().cpu().numpy().astype(np.complex128).reshape(F, H, W)
+        for f in range(F):
+            M = At[f]
+            peak = np.abs(M).max()
+            if not np.isfinite(peak) or peak == 0.0:
+                return None
+            yc, xc = np.unravel_index(np.argmax(np.abs(M)), M.shape)
+            fx = M[yc, :].copy()
+            fy = M[:, xc] / M[yc, xc]
+            if np.abs(np.outer(fy, fx) - M).max() > tol * peak:
+                return None
+            # ey -> c ey, ex -> ex / c with c^2 ey[y] ey[H-1-y] real positive
+            prod = (fy * fy[::-1]).sum()
+            if np.abs(prod) > 0:
+                c = np.exp(-0.5j * np.angle(prod))
+                gy, gx = fy * c, fx / c
+                asym = np.abs(gy[::-1] - np.conj(gy)).max()
+                if asym <= tol * np.abs(gy).max():
+                    fy, fx = 0.5 * (gy + np.conj(gy[::-1])), gx
+            ey[t, f], ex[t, f] = fy, fx
+    return ey, ex
+
+
 def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -206,10 +244,16 @@ class BlackHoleImagingTorch(Operator):
     @classmethod
     def from_tensors(cls, A_vis, sigma, cp_index, cp_conjugate, camp_index, camp_conjugate,
                      imsize, w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.5,
-                     loss_normalize=True, device='cuda'):
-        """Operator around an arbitrary dense ``A_vis`` ([1,T,F,H*W] or [T,F,H*W] complex) and
-        the reference's index tensors -- the attributes the reference keeps (blackhole.py:155-163).
-        ``sigma`` is the per-visibility sigma already divided by ref_multiplier."""
+                     loss_normalize=True, device='cuda', dft='auto'):
+        """Operator around a dense ``A_vis`` ([1,T,F,H*W] or [T,F,H*W] complex) and the
+        reference's index tensors -- the attributes the reference keeps (blackhole.py:155-163).
+        ``sigma`` is the per-visibility sigma already divided by ref_multiplier.
+
+        ``dft='auto'`` looks for the rank-1 structure ehtim's ftmatrix gives every row
+        (``A[t,f] = ey (x) ex`` as an H x W matrix): if every row factors to fp32 rounding the
+        separable kernels are used (``factor_A_vis``), otherwise -- or with ``dft='dense'`` -- the
+        matrix is streamed as given."""
+        assert dft in ("auto", "sep3", "sep", "dense"), dft
         self = cls.__new__(cls)
         Operator.__init__(self, 0)
         self.device = torch.device(device)
@@ -220,7 +264,23 @@ class BlackHoleImagingTorch(Operator):
         assert H * W == HW
         self._init_common(T, F, H, W, sigma.float(), cp_index, cp_conjugate, camp_index,
                           camp_conjugate, w_vis, w_amp, w_cphase, w_logcamp, w_flux, loss_normalize)
-        self._init_dense(A.to(device=self.device, dtype=torch.complex64).contiguous())
+        factors = None
+        if dft != "dense" and F <= 31 and H % 32 == 0 and W % 32 == 0 and max(H, W) <= 512:
+            factors = factor_A_vis(A, H, W)
+        if factors is None:
+            if dft in ("sep", "sep3"):
+                raise ValueError("dft=%r: A_vis is not rank-1 per baseline to fp32 rounding" % dft)
+            self._init_dense(A.to(device=self.device, dtype=torch.complex64).contiguous())
+            return self
+        self._init_sep(*factors)
+        self._A_vis = A.to(device=self.device, dtype=torch.complex64).contiguous().unsqueeze(0)
+        L = _lib.lib()
+        sep3_ok = bool(L.bh_sep3_supported(H, W)) and \
+            bool(L.bh_sep3_tables_ok(_lib.ptr(self._ey_ri_host), T, H))
+        if dft == "sep3" and not sep3_ok:
+            raise ValueError("dft='sep3' needs a square 256/128/64 image and a mirror-symmetric grid")
+        if dft in ("auto", "sep3") and sep3_ok:
+            self.path = "sep3"
         return self
 
     @staticmethod

@@ -132,3 +132,22 @@ def test_array_file_synthesis_shapes():
     assert cp_i.shape == (len(tab["tri"]), 3) and int(cp_i.max()) < T * F
     # frame t's closures only touch frame t's rows (time is part of the key)
     assert torch.equal(cp_i // F, (torch.arange(len(cp_i)) // (len(cp_i) // T))[:, None].expand(-1, 3))
+
+
+def test_factor_A_vis_recovers_mirror_symmetric_factors():
+    """Rank-1 factor extraction from a dense complex64 A_vis (the from_tensors drop-in route):
+    reproduces the matrix to fp32 rounding, yields bit-exactly conjugate-symmetric fp32 tables on a
+    centred grid, and refuses matrices without the structure."""
+    import torch
+    from step_amd import eht_lite
+    from step_amd.forward_operator.blackhole import factor_A_vis
+    tab = eht_lite.synthetic_table(5, 64, seed=3)
+    ey, ex = eht_lite.ft_factors(np.asarray(tab["uv"], dtype=np.float64)[:3], 32, 64, eht_lite.PSIZE)
+    A = torch.from_numpy(eht_lite.dense_from_factors(ey, ex)).to(torch.complex64)
+    gy, gx = factor_A_vis(A, 32, 64)
+    rec = (gy[..., :, None] * gx[..., None, :]).reshape(A.shape)
+    assert np.abs(rec - A.numpy()).max() <= 3e-7 * np.abs(A.numpy()).max()
+    r32, i32 = gy.real.astype(np.float32), gy.imag.astype(np.float32)
+    assert np.array_equal(r32[..., ::-1], r32) and np.array_equal(i32[..., ::-1], -i32)
+    assert factor_A_vis(torch.randn(2, 3, 32 * 64, dtype=torch.complex64), 32, 64) is None
+    assert factor_A_vis(torch.zeros(1, 2, 32 * 64, dtype=torch.complex64), 32, 64) is None
