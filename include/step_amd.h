@@ -125,9 +125,14 @@ int bh_sep3_tables_ok(const float* ey_ri_host, int T, int H);
 int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int F, int H, int W,
                     const float* x, int B, float scale, float shift, float clip_min,
                     float* vis_c64, float* flux, void* stream);
+/* sum_out (may be NULL) = sum(sum_in[0 .. sum_n)) in a fixed order, computed by one wave of the
+ * same launch: the scalar loss of gradient(x, y, return_loss=True) (base.py:43-49, daps.py:100)
+ * without a reduction launch of its own.  sum_in must be complete before this launch starts
+ * (same stream as its producer). */
 int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
                     const float* gvis_c64, const float* gflux, const float* chain_scale,
-                    int B, float out_scale, float* grad, void* stream);
+                    int B, float out_scale, float* grad, const float* sum_in, int sum_n,
+                    float* sum_out, void* stream);
 
 /* ------------------------------------------------------------------ closure quantities */
 

@@ -62,7 +62,8 @@ SIGNATURES = {
     "bh_sep3_supported": (c_i, [c_i, c_i]),
     "bh_sep3_tables_ok": (c_i, [c_p, c_i, c_i]),
     "bh_dft_fwd_sep3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_f, c_f, c_p, c_p, c_p]),
-    "bh_dft_adj_sep3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p]),
+    "bh_dft_adj_sep3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_i,
+                              c_p, c_p]),
     "bh_closure_loss": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
                               C.POINTER(bh_weights_t), c_p, c_p, c_p, c_p, c_p]),
     "bh_closure_chisq": (c_i, [c_p, c_p, c_i, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),

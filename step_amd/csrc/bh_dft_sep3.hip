@@ -305,9 +305,17 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
     const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, int B, int cpw,
-    float out_scale) {
+    float out_scale, const float* __restrict__ sum_in, int sum_n, float* __restrict__ sum_out) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
     constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
+    // optional rider: sum_out = sum(sum_in[0 .. sum_n)) in a fixed order (the scalar loss that
+    // gradient(return_loss=True) returns, daps.py:100) -- saves a reduction launch per step
+    if (sum_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        float sacc = 0.f;
+        for (int i = threadIdx.x; i < sum_n; i += 64) sacc += sum_in[i];
+        sacc = wave_sum(sacc);
+        if (threadIdx.x == 0) *sum_out = sacc;
+    }
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
     u32x4* eyp = lds4;
     const int t = blockIdx.y, b0 = blockIdx.x * cpw;
@@ -406,27 +414,29 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
 template <int H, int W>
 static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, const float* gvis,
                           const float* gflux, const float* chain_scale, int B, float out_scale,
-                          float* grad, hipStream_t st) {
+                          float* grad, const float* sum_in, int sum_n, float* sum_out, hipStream_t st) {
     int cpw, gx;
     s3_grid(B, T, &cpw, &gx);
     const size_t lds = (size_t)24 * (H / 2) * 16;
     step_allow_lds((const void*)k_dft_adj_s3<H, W>, lds);
     hipLaunchKernelGGL((k_dft_adj_s3<H, W>), dim3(gx, T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
-                       gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale);
+                       gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out);
 }
 
 extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
                                const float* gvis_c64, const float* gflux, const float* chain_scale,
-                               int B, float out_scale, float* grad, void* stream) {
+                               int B, float out_scale, float* grad, const float* sum_in, int sum_n,
+                               float* sum_out, void* stream) {
     STEP_REQUIRE(ey_ri && ex_ri && gvis_c64 && gflux && grad, "bh_dft_adj_sep3: null pointer");
+    STEP_REQUIRE(!sum_out || (sum_in && sum_n > 0), "bh_dft_adj_sep3: sum_out needs sum_in and sum_n > 0");
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_adj_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
     hipStream_t st = (hipStream_t)stream;
-    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
-    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
+    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
+    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
 
-    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, st);
+    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3");
     return STEP_OK;
 }

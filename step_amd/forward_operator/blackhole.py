@@ -434,25 +434,36 @@ class BlackHoleImagingTorch(Operator):
         _lib.check(rc, "bh_dft_fwd_" + self.path)
         return torch.view_as_complex(vis), flux
 
-    def _adjoint(self, gvis, gflux, chain_scale, out_scale):
-        """gvis [B, T*F, 2] fp32, gflux [B, T] -> grad [B, T, H*W] fp32."""
+    def _adjoint(self, gvis, gflux, chain_scale, out_scale, sum_of=None):
+        """gvis [B, T*F, 2] fp32, gflux [B, T] -> grad [B, T, H*W] fp32.
+        sum_of: a 1-d fp32 tensor whose sum the caller also wants (-> (grad, 0-d sum));
+        on the sep3 path it rides along in the adjoint launch."""
         B = gvis.shape[0]
         grad = torch.empty(B, self.T, self.H * self.W, device=self.device, dtype=torch.float32)
         L, st = _lib.lib(), _lib.stream_of(grad)
         cs = None if chain_scale is None else chain_scale.data_ptr()
         t0 = self._tick()
-        if self.path in ("sep", "sep3"):
-            fn = L.bh_dft_adj_sep3 if self.path == "sep3" else L.bh_dft_adj_sep
-            rc = fn(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
-                    self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
-                    out_scale, grad.data_ptr(), st)
+        total = None
+        if self.path == "sep3":
+            if sum_of is not None:
+                total = torch.empty(1, device=self.device, dtype=torch.float32)
+            rc = L.bh_dft_adj_sep3(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                                   self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
+                                   out_scale, grad.data_ptr(), _lib.ptr(sum_of),
+                                   0 if sum_of is None else sum_of.numel(), _lib.ptr(total), st)
+        elif self.path == "sep":
+            rc = L.bh_dft_adj_sep(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                                  self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
+                                  out_scale, grad.data_ptr(), st)
         else:
             rc = L.bh_dft_adj_dense(self._a_rows.data_ptr(), self.T, self.F, self.H * self.W,
                                     gvis.data_ptr(), gflux.data_ptr(), cs, B, out_scale,
                                     grad.data_ptr(), st)
         self._tock("dft_adj", t0)
         _lib.check(rc, "bh_dft_adj_" + self.path)
-        return grad
+        if sum_of is None:
+            return grad
+        return grad, (total[0] if total is not None else sum_of.sum())
 
     def _meas(self, y):
         """bh_meas_t for a BlackHoleObservation (+ the tensors that must outlive the launch)."""
@@ -625,10 +636,10 @@ class BlackHoleImagingTorch(Operator):
         """Fused loss forward + adjoint (no autograd graph); same result as the base class's
         autograd.grad of loss(x, y).sum()  (base.py:43-49)."""
         loss, gvis, gflux = self._loss_forward(x, y, True)
-        grad = self._adjoint(gvis, gflux, None, 0.5).view(x.shape).to(x.dtype)
         if return_loss:
-            return grad, loss.sum()
-        return grad
+            grad, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss)
+            return grad.view(x.shape).to(x.dtype), total
+        return self._adjoint(gvis, gflux, None, 0.5).view(x.shape).to(x.dtype)
 
 
 def thermal_measure(op, x, generator=None):
