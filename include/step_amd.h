@@ -223,13 +223,15 @@ typedef struct {
     float sqrt_2lr;      /* np.sqrt(2 lr)      daps.py:137 */
     float momentum;      /* daps.py:140 */
     float noise_scale;   /* np.sqrt(2 (1 - momentum)) */
-    int32_t algo;        /* 0 = langevin, 1 = hmc */
+    int32_t algo;        /* 0 = langevin, 1 = hmc, 2 = gradient descent of optimize() */
 } mcmc_params_t;
 
 /* score = -grad*inv_tau2 + (xt - x)*inv_sigma2 + prior  (score_fn daps.py:93-104), then
  * mc_update daps.py:135-144 in place on x (and velocity for hmc).  Sets *nan_flag (int32,
  * device) to 1 if any updated x is NaN (the guard of daps.py:202-203 without a per-step sync
- * unless the host chooses to read it). */
+ * unless the host chooses to read it).
+ * algo 2: x -= lr * (grad + (x - xt) * inv_sigma2) with xt = x0hat (MCMCSampler.optimize,
+ * daps.py:210-223); velocity, prior and eps are not read and may be NULL. */
 int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, const float* prior,
                 const float* eps, int64_t n, const mcmc_params_t* p, int32_t* nan_flag,
                 void* stream);

@@ -5,6 +5,7 @@
 //   score = -grad / tau^2 + (xt - x) / sigma^2 + prior
 //   langevin: x += lr * score + sqrt(2 lr) * eps
 //   hmc:      v  = momentum * v + sqrt(lr) * score + sqrt(2 (1 - momentum)) * eps ;  x += sqrt(lr) * v
+//   optimize (algo 2, daps.py:210-223):  x -= lr * (grad + (x - xt) / sigma^2)   with xt = x0hat
 // The python scalars of the reference (np.sqrt results, float64) enter fp32 tensor ops as fp32
 // scalars; here they arrive already rounded to fp32 in mcmc_params_t.
 #include "common.h"
@@ -13,6 +14,10 @@
 // configuration runs hmc with momentum 0, where the old velocity has weight zero).
 __device__ __forceinline__ float mcmc_elem(float xi, float g, float xti, float pr, float e, float v_old,
                                            const mcmc_params_t& p, float& v_new) {
+    if (p.algo == 2) {   // MCMCSampler.optimize, daps.py:210-223: x -= lr (g + (x - x0hat) / sigma^2)
+        v_new = 0.f;
+        return xi - p.lr * (g + (xi - xti) * p.inv_sigma2);
+    }
     const float s = -g * p.inv_tau2 + (xti - xi) * p.inv_sigma2 + pr;
     if (p.algo == 0) {
         v_new = 0.f;
@@ -41,7 +46,8 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             const f4 xi = ((const f4*)x)[i];
             const f4 g = __builtin_nontemporal_load((const f4*)grad + i);
-            const f4 e = __builtin_nontemporal_load((const f4*)eps + i);
+            f4 e = {0.f, 0.f, 0.f, 0.f};
+            if (eps) e = __builtin_nontemporal_load((const f4*)eps + i);
             const f4 xti = ((const f4*)xt)[i];
             f4 pr = {0.f, 0.f, 0.f, 0.f}, vo = {0.f, 0.f, 0.f, 0.f}, xn, vn;
             if (prior) pr = __builtin_nontemporal_load((const f4*)prior + i);
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             float v;
-            const float xn = mcmc_elem(x[i], grad[i], xt[i], prior ? prior[i] : 0.f, eps[i],
+            const float xn = mcmc_elem(x[i], grad[i], xt[i], prior ? prior[i] : 0.f, eps ? eps[i] : 0.f,
                                        rd_vel ? vel[i] : 0.f, p, v);
             if (p.algo == 1) vel[i] = v;
             x[i] = xn;
@@ -72,10 +78,11 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
 extern "C" int mcmc_update(float* x, float* velocity, const float* grad, const float* xt,
                            const float* prior, const float* eps, int64_t n, const mcmc_params_t* p,
                            int32_t* nan_flag, void* stream) {
-    STEP_REQUIRE(x && grad && xt && eps && p, "mcmc_update: null pointer");
+    STEP_REQUIRE(x && grad && xt && p, "mcmc_update: null pointer");
     STEP_REQUIRE(n > 0, "mcmc_update: n = %lld", (long long)n);
-    STEP_REQUIRE(p->algo == 0 || p->algo == 1, "mcmc_update: unknown algo %d", p->algo);
-    STEP_REQUIRE(p->algo == 0 || velocity, "mcmc_update: hmc needs a velocity buffer");
+    STEP_REQUIRE(p->algo >= 0 && p->algo <= 2, "mcmc_update: unknown algo %d", p->algo);
+    STEP_REQUIRE(p->algo != 1 || velocity, "mcmc_update: hmc needs a velocity buffer");
+    STEP_REQUIRE(p->algo == 2 || eps, "mcmc_update: langevin / hmc need the noise tensor");
     const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
                          (uintptr_t)prior | (uintptr_t)eps;
     const bool vec = (n % 4 == 0) && (al % 16 == 0);

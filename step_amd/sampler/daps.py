@@ -197,13 +197,26 @@ class MCMCSampler(nn.Module):
         return x.detach()
 
     def optimize(self, x0hat, operator, measurement, sigma, ratio, record=False, verbose=False):
+        """Pixel-space gradient descent on decoded frames (daps.py:210-223); the update
+        ``x -= lr (g + (x - x0hat) / sigma^2)`` is one fused kernel on the GPU."""
         lr = self.get_lr(ratio)
         x = x0hat.clone().detach()
+        fused = x.device.type == 'cuda' and x.dtype == torch.float32
+        if fused:
+            x = x.contiguous()
+            x0 = self._kernel_tensor(x0hat.detach(), x)
+            params = _lib.mcmc_params_t(1.0, 1.0 / float(sigma) ** 2, lr, 0.0, 0.0, 0.0, 0.0, 2)
         for _ in range(self.num_steps):
             g, loss = operator.gradient(x, measurement, return_loss=True)
-            x = x - lr * (g + (x - x0hat.detach()) / sigma ** 2)
+            if fused:
+                rc = _lib.lib().mcmc_update(x.data_ptr(), None, self._kernel_tensor(g, x).data_ptr(),
+                                            x0.data_ptr(), None, None, x.numel(), C.byref(params),
+                                            None, _lib.stream_of(x))
+                _lib.check(rc, "mcmc_update")
+            else:
+                x = x - lr * (g + (x - x0hat.detach()) / sigma ** 2)
             if record:
-                self._record(x, g, loss)
+                self._record(x.clone() if fused else x, g, loss)
         return x.detach()
 
     def _record(self, x, epsilon, loss):
