@@ -132,3 +132,50 @@ def edm_sigmas(num_steps, sigma_max=100, sigma_min=1e-2, timestep="poly-7"):
                   for s in r])
     t = torch.from_numpy(t).float()
     return torch.cat([t[:-1], torch.zeros_like(t[:1])])
+
+
+def edm_time_steps(num_steps, sigma_max, sigma_min, timestep="poly-7"):
+    """EDMScheduler.get_discrete_time_steps(self.num_steps), cores/scheduler.py:266-315: the
+    scheduler stores num_steps + 1 (:38) and the grid keeps numpy's float64 (torch.from_numpy
+    without .float(), :313-315); sigma_max may be a 0-d tensor (daps.py:300)."""
+    p = int(timestep.split("-")[1])
+    fn = lambda r: (sigma_max ** (1 / p) + r * (sigma_min ** (1 / p) - sigma_max ** (1 / p))) ** p
+    return torch.from_numpy(np.array([fn(s) for s in np.linspace(0, 1, num_steps + 1)]))
+
+
+def pfode_euler_oracle(model, ts, xT):
+    """DiffusionPFODE.sample with method='euler' (cores/scheduler.py:378-408) for the EDM
+    schedule (s = 1, sigma(t) = t): dx/dt = -t score(x, sigma=t); fixed-grid Euler on ts (what
+    torchdiffeq's 'euler' does -- restated from its published behaviour, unpinned)."""
+    x = xT.flatten(1)
+    for i in range(len(ts) - 1):
+        t = ts[i]
+        d = -1.0 * torch.ones_like(t.float()) * t.float() * model.score(x.view(xT.shape), sigma=t.float())
+        x = x + (ts[i + 1] - t) * d.flatten(1)
+    return x.view(xT.shape)
+
+
+class LatentDAPSOracle:
+    """LatentDAPS.sample, sampler/daps.py:254-382 (no evaluator / recorder)."""
+
+    def __init__(self, ann, dif, mc, latent_wrapper=True):
+        self.sigmas = edm_sigmas(ann["num_steps"], ann["sigma_max"], ann["sigma_min"], ann["timestep"])
+        self.n = ann["num_steps"] + 1
+        self.dif, self.mc, self.wrap = dif, MCMCOracle(**mc), latent_wrapper
+
+    def sample(self, model, z_start, op, y):
+        oper = LatentWrapOracle(op, model) if self.wrap else op
+        zt = z_start
+        for step in range(self.n - 1):
+            sigma = self.sigmas[step]
+            with torch.no_grad():
+                ts = edm_time_steps(self.dif["num_steps"], sigma, self.dif["sigma_min"], self.dif["timestep"])
+                z0hat = pfode_euler_oracle(model, ts, zt)
+                x0hat = model.decode(z0hat)
+            ratio = step / self.n
+            if self.wrap:
+                z0y = self.mc.sample(zt, model, z0hat, oper, y, sigma, ratio)
+            else:
+                z0y = model.encode(self.mc.optimize(x0hat, op, y, sigma, ratio))
+            zt = z0y + torch.randn_like(z0y) * self.sigmas[step + 1]
+        return model.decode(zt)

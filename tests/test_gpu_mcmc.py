@@ -92,3 +92,36 @@ def test_nan_guard_returns_zeros(setup, dev):
         s = MCMCSampler(num_steps=3, lr=1e-6, tau=1.0, prior_solver="gaussian", nan_check=mode)
         out = s.sample(x0hat, model, x0hat, op, y, 0.7, 0.25)
         assert out.shape == x0hat.shape and torch.count_nonzero(out).item() == 0
+
+
+DAPS_CASES = {
+    "latent": (dict(num_steps=3, lr=1.2e-5, tau=0.021, lr_min_ratio=0.015, prior_solver="exact",
+                    mc_algo="hmc", momentum=0.0), True),
+    "latent_mom": (dict(num_steps=3, lr=1.2e-4, tau=0.1, lr_min_ratio=0.011, prior_solver="gaussian",
+                        mc_algo="hmc", momentum=0.83), True),
+    "pixel": (dict(num_steps=3, lr=2e-7, tau=1.0), False),
+}
+
+
+@pytest.mark.parametrize("case", list(DAPS_CASES))
+def test_latent_daps_matches_reference(case, golden, dev):
+    """The whole annealing driver (PF-ODE denoise -> MCMC / optimize -> re-noise, reference
+    sampler/daps.py:254-382) against the reference's own LatentDAPS.sample on the bh_small operator,
+    with the reference's noise draws replayed (tests/golden/daps_bh_small.npz)."""
+    from step_amd.sampler import LatentDAPS
+    g, d = golden("bh_small"), golden("daps_bh_small")
+    op, y = make_dense_op(g, dev), make_y(g, dev)
+    model = ToyModel((64, 1, 8, 8), factor=2, gain=float(d["toy_gain"])).to(dev)
+    mc, wrap = DAPS_CASES[case]
+    for k, v in mc.items():
+        if not isinstance(v, str):
+            assert float(d["%s_mc_%s" % (case, k)]) == float(v)
+    ann = dict(name="edm", num_steps=int(d["ann_num_steps"]), sigma_max=float(d["ann_sigma_max"]),
+               sigma_min=float(d["ann_sigma_min"]), timestep="poly-7")
+    dif = dict(name="edm", num_steps=int(d["dif_num_steps"]), sigma_min=float(d["dif_sigma_min"]),
+               timestep="poly-7")
+    s = LatentDAPS(ann, dif, mc, latent_wrapper=wrap)
+    with Replay(list(t(d[case + "_noise"]))) as tape:
+        out = s.sample(model, t(d[case + "_z_start"], dev), op, y)
+    assert not tape.n, "the reference drew %d more noise tensors" % len(tape.n)
+    assert_close(out, d[case + "_result"], TRAJ_TOL, "LatentDAPS " + case)

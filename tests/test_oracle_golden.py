@@ -109,3 +109,21 @@ def test_edm_sigma_grid(golden):
     e = golden("edm_sigmas")
     assert torch.equal(edm_sigmas(25), t(e["s25"])) and torch.equal(edm_sigmas(20), t(e["s20"]))
     assert len(e["s25"]) == 26 and e["s25"][0] == 100 and e["s25"][-1] == 0
+
+
+def test_latent_daps_oracle_matches_reference(golden):
+    """The annealing driver restated (oracle.mcmc_oracle.LatentDAPSOracle) against the reference's own
+    LatentDAPS.sample (tests/golden/daps_bh_small.npz, reference noise replayed)."""
+    from oracle.mcmc_oracle import LatentDAPSOracle
+    from tests.test_gpu_mcmc import DAPS_CASES, Replay
+    g, d = golden("bh_small"), golden("daps_bh_small")
+    orc, y = oracle_from_golden(g), obs_from_golden(g, "y_")
+    model = ToyModel((64, 1, 8, 8), factor=2, gain=float(d["toy_gain"]))
+    ann = dict(num_steps=int(d["ann_num_steps"]), sigma_max=float(d["ann_sigma_max"]),
+               sigma_min=float(d["ann_sigma_min"]), timestep="poly-7")
+    dif = dict(num_steps=int(d["dif_num_steps"]), sigma_min=float(d["dif_sigma_min"]), timestep="poly-7")
+    for case, (mc, wrap) in DAPS_CASES.items():
+        with Replay(list(t(d[case + "_noise"]))) as tape:
+            out = LatentDAPSOracle(ann, dif, mc, latent_wrapper=wrap).sample(model, t(d[case + "_z_start"]), orc, y)
+        assert not tape.n
+        close(out, d[case + "_result"], 1e-4)
