@@ -149,3 +149,26 @@ def test_write_sample_dir_layout(tmp_path):
     assert names == ["observations.pth", "sample_0.pth", "sample_1.pth", "sample_2.pth", "videos.pth"]
     assert torch.equal(torch.load(tmp_path / "0007" / "sample_2.pth", weights_only=True), samples[2:3])
     assert torch.equal(load_observation(tmp_path / "0007" / "observations.pth").flux, obs.flux)
+
+
+def test_blackhole_observation_container_semantics():
+    """a18: the nine-field container behaves like reference forward_operator/blackhole.py:23-132."""
+    import torch
+    from step_amd.forward_operator import BlackHoleObservation
+    names = ("vis", "sigma_vis", "amp", "sigma_amp", "cphase", "sigma_cphase", "logcamp",
+             "sigma_logcamp", "flux")
+    f = [torch.full((3, 4), float(i)) for i in range(9)]
+    o = BlackHoleObservation(*f)
+    assert len(o) == 3
+    assert [float(x[0, 0]) for x in o.to_list()] == list(range(9))          # to_list order
+    assert list(o.to_dict()) == list(names)
+    assert o[1:3].amp.shape == (2, 4) and o[0].flux.shape == (4,)
+    m = BlackHoleObservation.merge([o, o[0:1]])
+    assert len(m) == 4 and torch.equal(m.cphase[3], o.cphase[0])
+    assert o.to("cpu").vis is not None and type(o.to("cpu")) is BlackHoleObservation
+    g = torch.ones(2, 2, requires_grad=True)
+    p = BlackHoleObservation(cphase=g * 2, sigma_cphase=g * 3)              # partial observation
+    assert set(p.to_dict()) == {"cphase", "sigma_cphase"} and p[0].vis is None
+    assert p.detach() is None and not p.cphase.requires_grad                # in place, like the reference
+    q = BlackHoleObservation().from_dict({"flux": f[8], "amp": f[2], "sigma_amp": f[3]})
+    assert q.flux is f[8] and q.amp is f[2] and q.vis is None
