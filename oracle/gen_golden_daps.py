@@ -75,6 +75,32 @@ def main():
                 out["%s_mc_%s" % (name, k)] = v
     G.npz("daps_bh_small", **out)
 
+    # the MRI task's shipped sampler algorithm (hmc, momentum 0.83, exact prior, lr 1.2e-3;
+    # configs/task/mri.yaml:48-56) on the reference's own 'mri' operator, two annealing steps, one
+    # chain.  tau is 30 instead of 0.1: with the toy decoder the shipped value makes lr/tau^2 times
+    # the loss curvature ~1e4, a chaotic map on which fp32 rounding differences grow to 1e-3 in
+    # three steps -- no yardstick for parity
+    mop = fo.get_operator("mri", acc_factor=6, mode="same_mask", resolution=192, frames=12,
+                          num_acs_lines=24)
+    g = torch.Generator().manual_seed(38)
+    ym = mop(torch.randn(1, 12, 2, 192, 192, generator=g))
+    mmodel = ToyModel((12, 2, 48, 48), factor=4, gain=0.5)
+    mc = dict(num_steps=3, lr=1.2e-3, tau=30.0, lr_min_ratio=0.011, prior_solver="exact",
+              mc_algo="hmc", momentum=0.83)
+    torch.manual_seed(43)
+    s = LatentDAPS(dict(name="edm", num_steps=2, sigma_max=10, sigma_min=1e-2, timestep="poly-7"),
+                   dict(name="edm", num_steps=3, sigma_min=1e-5, timestep="poly-7"), dict(mc),
+                   latent_wrapper=True)
+    z_start = torch.randn(1, 12, 2, 48, 48) * s.annealing_scheduler.sigma_max
+    with G.NoiseTape() as tape:
+        res = s.sample(mmodel, z_start, mop, ym)
+    assert torch.isfinite(res).all()
+    # the measurement is stored as its kept k-space rows only (the masked-out rows are exactly 0)
+    rows = torch.nonzero(mop.mask.flatten()).flatten()
+    assert torch.count_nonzero(ym) == torch.count_nonzero(ym[:, :, :, rows])
+    G.npz("daps_mri_small", z_start=z_start, noise=torch.stack(tape.items), result=res,
+          y_rows=ym[:, :, :, rows], rows=rows, toy_gain=0.5)
+
 
 if __name__ == "__main__":
     main()

@@ -125,3 +125,31 @@ def test_latent_daps_matches_reference(case, golden, dev):
         out = s.sample(model, t(d[case + "_z_start"], dev), op, y)
     assert not tape.n, "the reference drew %d more noise tensors" % len(tape.n)
     assert_close(out, d[case + "_result"], TRAJ_TOL, "LatentDAPS " + case)
+
+
+MRI_DAPS = dict(ann=dict(name="edm", num_steps=2, sigma_max=10, sigma_min=1e-2, timestep="poly-7"),
+                dif=dict(name="edm", num_steps=3, sigma_min=1e-5, timestep="poly-7"),
+                mc=dict(num_steps=3, lr=1.2e-3, tau=30.0, lr_min_ratio=0.011, prior_solver="exact",
+                        mc_algo="hmc", momentum=0.83))
+
+
+def mri_measurement(d):
+    y = torch.zeros(1, 12, 2, 192, 192)
+    y[:, :, :, t(d["rows"]).long()] = t(d["y_rows"])
+    return y
+
+
+def test_latent_daps_mri_matches_reference(golden, dev):
+    """The MRI task's sampler algorithm (hmc, momentum 0.83, exact prior; configs/task/mri.yaml:48-56,
+    tau relaxed so that the chain is not chaotic under the toy decoder) through LatentWrapper and
+    the fused MRI kernels, against the reference's LatentDAPS.sample."""
+    from step_amd.forward_operator import get_operator
+    from step_amd.sampler import LatentDAPS
+    d = golden("daps_mri_small")
+    op = get_operator("mri", acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+    model = ToyModel((12, 2, 48, 48), factor=4, gain=float(d["toy_gain"])).to(dev)
+    s = LatentDAPS(MRI_DAPS["ann"], MRI_DAPS["dif"], MRI_DAPS["mc"], latent_wrapper=True)
+    with Replay(list(t(d["noise"]))) as tape:
+        out = s.sample(model, t(d["z_start"], dev), op, mri_measurement(d).to(dev))
+    assert not tape.n
+    assert_close(out, d["result"], TRAJ_TOL, "LatentDAPS mri")

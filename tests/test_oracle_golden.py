@@ -127,3 +127,16 @@ def test_latent_daps_oracle_matches_reference(golden):
             out = LatentDAPSOracle(ann, dif, mc, latent_wrapper=wrap).sample(model, t(d[case + "_z_start"]), orc, y)
         assert not tape.n
         close(out, d[case + "_result"], 1e-4)
+
+
+def test_latent_daps_oracle_matches_reference_mri(golden):
+    from oracle.mcmc_oracle import LatentDAPSOracle
+    from tests.test_gpu_mcmc import MRI_DAPS, Replay, mri_measurement
+    d = golden("daps_mri_small")
+    orc = MRIOracle(6, "same_mask", 192, 12, 24)
+    model = ToyModel((12, 2, 48, 48), factor=4, gain=float(d["toy_gain"]))
+    with Replay(list(t(d["noise"]))) as tape:
+        out = LatentDAPSOracle(MRI_DAPS["ann"], MRI_DAPS["dif"], MRI_DAPS["mc"]).sample(
+            model, t(d["z_start"]), orc, mri_measurement(d))
+    assert not tape.n
+    close(out, d["result"], 1e-4)
