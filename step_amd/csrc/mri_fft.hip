@@ -258,12 +258,18 @@ __device__ __forceinline__ void load_tables(const MriLds& L, const int* __restri
         L.rowl[e] = r;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < MRI_R; e += MRI_THREADS) {
-        if (L.rowpos[e] < 0) {                      // rank among the masked-out rows
-            int rank = 0;
-            for (int q = 0; q < e; ++q) rank += L.rowpos[q] < 0;
-            L.unrow[rank] = e;
-        }
+    // rank of every masked-out row among the masked-out rows: ballot + popcount within each of
+    // the three waves that cover the 192 rows, wave totals through LDS (red[0..2])
+    const int e = threadIdx.x;
+    const bool out_row = e < MRI_R && L.rowpos[e] < 0;
+    const unsigned long long m = __ballot(out_row);
+    const int below = __popcll(m & ((1ull << (e & 63)) - 1ull));
+    if (e < MRI_R && (e & 63) == 0) L.red[e >> 6] = (float)__popcll(m);
+    __syncthreads();
+    if (out_row) {
+        int base = 0;
+        for (int w = 0; w < (e >> 6); ++w) base += (int)L.red[w];
+        L.unrow[base + below] = e;
     }
     __syncthreads();
 }
