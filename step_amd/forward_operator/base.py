@@ -2,61 +2,51 @@
 (reference forward_operator/base.py:8-55): same registry names, same method
 signatures, same error behaviour (re-registration warns and overwrites, an
 unknown name raises NameError)."""
-import warnings
 from abc import ABC, abstractmethod
 
 import torch
 
+from .._registry import Registry
+
 __all__ = ["Operator", "register_operator", "get_operator"]
 
-__OPERATOR__ = {}
-
-
-def register_operator(name: str):
-    def wrapper(cls):
-        prev = __OPERATOR__.get(name, None)
-        if prev and prev != cls:
-            warnings.warn(f"Name {name} is already registered!", UserWarning)
-        __OPERATOR__[name] = cls
-        cls.name = name
-        return cls
-    return wrapper
-
-
-def get_operator(name: str, **kwargs):
-    if __OPERATOR__.get(name, None) is None:
-        raise NameError(f"Name {name} is not defined.")
-    return __OPERATOR__[name](**kwargs)
+__OPERATOR__ = Registry("operator")
+register_operator = __OPERATOR__.register
+get_operator = __OPERATOR__.create
 
 
 class Operator(ABC):
-    """y = A(x) + noise.  Subclasses provide ``__call__``; the kernel-backed subclasses also
-    override ``loss``/``gradient`` with fused paths but keep these semantics."""
+    """y = A(x) + noise.  Interface of the reference's base class (forward_operator/base.py:28-55):
+    ``__call__`` is the noiseless operator; the generic ``loss`` / ``gradient`` below go through
+    torch autograd and are what the kernel-backed subclasses replace with fused launches while
+    keeping the same return values."""
 
     def __init__(self, sigma=0.05):
-        self.sigma = sigma
+        self.sigma = sigma                      # measurement noise level, read by LatentWrapper
 
     @abstractmethod
     def __call__(self, x):
-        pass
+        """Noiseless measurement A(x)."""
 
     def measure(self, x):
-        y0 = self(x)
-        return y0 + self.sigma * torch.randn_like(y0)
+        """A(x) plus white Gaussian noise of standard deviation ``sigma``."""
+        clean = self(x)
+        return clean + torch.randn_like(clean) * self.sigma
 
     def loss(self, x, y):
-        return ((self(x) - y) ** 2).flatten(1).sum(-1)
+        """Squared residual per chain: [B, ...] -> [B]."""
+        residual = self(x) - y
+        return residual.pow(2).flatten(start_dim=1).sum(dim=-1)
 
     def gradient(self, x, y, return_loss=False):
-        x_tmp = x.clone().detach().requires_grad_(True)
-        loss = self.loss(x_tmp, y).sum()
-        x_grad = torch.autograd.grad(loss, x_tmp)[0]
-        if return_loss:
-            return x_grad, loss
-        return x_grad
+        """d/dx of the loss summed over the batch; with ``return_loss`` also that scalar."""
+        leaf = x.detach().clone().requires_grad_(True)
+        total = self.loss(leaf, y).sum()
+        (grad,) = torch.autograd.grad(total, leaf)
+        return (grad, total) if return_loss else grad
 
     def log_likelihood(self, x, y):
-        return -self.loss(x, y) / 2 / self.sigma ** 2
+        return self.loss(x, y) / (-2.0 * self.sigma ** 2)
 
     def likelihood(self, x, y):
-        return torch.exp(self.log_likelihood(x, y))
+        return self.log_likelihood(x, y).exp()

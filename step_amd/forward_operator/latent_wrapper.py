@@ -7,23 +7,26 @@ from .base import Operator
 
 
 class LatentWrapper(Operator):
+    """``op`` seen from latent space through ``model.decode``.  The operator's ``loss`` is a
+    torch.autograd.Function whose backward is the fused adjoint kernel, so the only autograd
+    work here is the decoder's own backward."""
+
     def __init__(self, op, model):
-        super().__init__(sigma=op.sigma)
-        self.op = op
-        self.model = model
+        Operator.__init__(self, sigma=op.sigma)
+        self.op, self.model = op, model
 
-    def __call__(self, x):
-        return self.op(self.model.decode(x))
+    def _decode(self, z):
+        return self.model.decode(z)
 
-    def loss(self, pred, observation):
-        decoded = self.model.decode(pred)
-        return self.op.loss(decoded.float(), observation)
+    def __call__(self, z):
+        return self.op(self._decode(z))
 
-    def gradient(self, pred, observation, return_loss=False):
-        pred_tmp = pred.clone().detach().requires_grad_(True)
-        loss = self.loss(pred_tmp, observation).sum()
-        pred_grad = torch.autograd.grad(loss, pred_tmp)[0]
-        pred_grad = torch.clamp(pred_grad.to(pred.dtype), -1, 1)
-        if return_loss:
-            return pred_grad, loss
-        return pred_grad
+    def loss(self, z, measurement):
+        return self.op.loss(self._decode(z).float(), measurement)          # fp32 into the kernels
+
+    def gradient(self, z, measurement, return_loss=False):
+        leaf = z.detach().clone().requires_grad_(True)
+        total = self.loss(leaf, measurement).sum()
+        (g,) = torch.autograd.grad(total, leaf)
+        g = g.to(z.dtype).clamp_(min=-1.0, max=1.0)                        # latent_wrapper.py:24-26
+        return (g, total) if return_loss else g
