@@ -219,6 +219,11 @@ def main():
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)
+        # BASELINE.json's second metric, derived: Langevin steps per posterior sample at the shipped
+        # configs; operator work only, the prior network is not in this bench
+        per_sample = 1500 if a.task == "blackhole" else 1060
+        out["derived"] = dict(samples_per_hour_operator_only=3600.0 * out["value"] / per_sample,
+                              langevin_steps_per_sample=per_sample)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = (cpu_baseline_blackhole(tab, a.cpu_reps) if a.task == "blackhole"
                                    else cpu_baseline_mri(a.cpu_reps * 4))
