@@ -16,6 +16,7 @@
 // gradient then accumulates over groups).
 #include "common.h"
 #include "fft_small.h"
+#include "mri_lg2.h"
 
 #ifdef EXP_MRI_TIMING   // experiment builds only: phase timestamps of workgroup 0
 __device__ unsigned long long g_mri_t[16];
@@ -388,6 +389,65 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
     if (tid == 0) loss_part[frame] = tot;
 }
 
+// ------------------------------------------------------- loss + gradient, pipelined (mri_lg2.h)
+struct Lg2DevCtx {
+    float* lds_;
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int block() const { return blockIdx.x; }
+    __device__ __forceinline__ int nblocks() const { return gridDim.x; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ float* lds() const { return lds_; }
+    // experiment builds only (EXP_MRI_TIMING): phase timestamps of workgroup 0
+    __device__ __forceinline__ void tick(int i, int frame) const {
+#ifdef EXP_MRI_TIMING
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_mri_t[i] = wall_clock64();
+#endif
+    }
+    __device__ __forceinline__ cf32 cos_sin_2pi_over_192(int e) const {
+        float sn, cn;
+        sincospif((float)e * (1.0f / 96.0f), &sn, &cn);
+        return c_make(cn, sn);
+    }
+    // rank of every masked-out row among the masked-out rows: ballot + popcount within each of
+    // the three waves that cover the 192 rows, wave totals through LDS (red[0..2])
+    __device__ __forceinline__ void rank_unkept(const int* rowpos, int* unrow, float* red) const {
+        const int e = threadIdx.x;
+        const bool out_row = e < MRI_R && rowpos[e] < 0;
+        const unsigned long long m = __ballot(out_row);
+        const int below = __popcll(m & ((1ull << (e & 63)) - 1ull));
+        if (e < MRI_R && (e & 63) == 0) red[e >> 6] = (float)__popcll(m);
+        __syncthreads();
+        if (out_row) {
+            int base = 0;
+            for (int w = 0; w < (e >> 6); ++w) base += (int)red[w];
+            unrow[base + below] = e;
+        }
+        __syncthreads();
+    }
+};
+
+__global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2(
+    const float* __restrict__ x, const float* __restrict__ y, int y_batch,
+    const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T,
+    int nframes, int nkc, const float* __restrict__ chain_scale, float* __restrict__ loss_part,
+    float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Lg2DevCtx ctx{lds};
+    lg2_body(ctx, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part,
+             grad);
+}
+
+// STEP_MRI_KERNEL=1 pins the first-generation kernel (experiments, cross-checks in the tests)
+static int mri_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("STEP_MRI_KERNEL");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------- adjoint only
 // out = A^H g = ifftshift( R^2 * IFFT2( M * g ) ): the vector-Jacobian product of mri_forward.
 __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
@@ -480,11 +540,21 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
     STEP_REQUIRE(y_batch == 1 || y_batch == B, "mri_loss_grad: measurement batch %d vs B=%d", y_batch, B);
     if (int rc = mri_check("mri_loss_grad", B, T, R, rows, nrows, mask_frames)) return rc;
     const int nkc = pick_nkc(max_rows);
-    const size_t lds = mri_lds_bytes(nkc);
-    step_allow_lds((const void*)k_mri_loss_grad, lds);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mri_loss_grad, dim3(B * T), dim3(MRI_THREADS), lds, s, x, y, y_batch, rows,
-                       nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
+    if (max_rows <= LG2_NKC_MAX && mri_variant() == 2) {
+        // every mask frame fits one row buffer: pipelined kernel
+        const size_t lds = lg2_lds_bytes(nkc);
+        const int nframes = B * T;
+        step_allow_lds((const void*)k_mri_loss_grad2, lds);
+        hipLaunchKernelGGL(k_mri_loss_grad2, dim3(nframes), dim3(LG2_THREADS),
+                           lds, s, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc,
+                           chain_scale, loss_part, grad);
+    } else {
+        const size_t lds = mri_lds_bytes(nkc);
+        step_allow_lds((const void*)k_mri_loss_grad, lds);
+        hipLaunchKernelGGL(k_mri_loss_grad, dim3(B * T), dim3(MRI_THREADS), lds, s, x, y, y_batch,
+                           rows, nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
+    }
     STEP_CHECK_LAUNCH("mri_loss_grad");
     hipLaunchKernelGGL(k_mri_loss_finish, dim3((B + 255) / 256), dim3(256), 0, s, loss_part, B, T, loss);
     STEP_CHECK_LAUNCH("mri_loss_finish");

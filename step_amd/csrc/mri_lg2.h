@@ -1,0 +1,431 @@
+// Dynamic-MRI Langevin step, second-generation body: forward FFT2 + mask + residual + loss +
+// adjoint of forward_operator/dynamic_mri.py:42-48 with base.py:40-41, fused per frame
+// (SURVEY Appendix B "MRI"), for masks whose kept rows fit one LDS row buffer (<= 64 rows).
+//
+// Same arithmetic as k_mri_loss_grad (mri_fft.hip) -- 192 = 16 x 12 in-register passes over LDS,
+// pruned to the kept k_y rows, fftshift folded into signs -- but scheduled differently:
+//   * software-pipelined column passes: while a thread transforms pass A of strip s (inputs
+//     loaded from global memory straight into the pass-A register layout, one strip ahead) it
+//     also finishes pass B of strip s-1 from registers; the strip buffer only carries the
+//     A -> B exchange: two barriers and 28 LDS accesses per thread and strip instead of three
+//     barriers and 83;
+//   * column-pass twiddles and row positions live in registers (constant per thread);
+//   * the row phase is three in-place passes: pass A, then pass B + residual + loss + the first
+//     pass of the inverse in the same registers (the inverse runs the transposed decomposition
+//     k = c + 16 d -> n = q + 12 p), then the inverse's 16-point pass;
+//   * row buffer padded 12 -> 13 per group (stride 208): both row-pass access patterns are
+//     conflict-free;
+//   * one workgroup per frame (a loop over frames inside the kernel carries the prefetched
+//     strip around the back edge and the register allocator then spills ~170 values, whose
+//     reloads wait behind every store in flight -- measured 1.5x slower than no loop).
+// The body is plain C++ over a small context (thread id, barrier, LDS base), so the same code
+// runs on the host under pthreads (tests/test_mri_lg2_host.py) and on the GPU.
+#pragma once
+#include "fft_small.h"
+
+#define LG2_R 192
+#define LG2_SW 32
+#define LG2_NS 6                  // strips per frame
+#define LG2_THREADS 512
+#define LG2_RS 208                // row-buffer stride in cf32: 16 groups of 12, each padded to 13
+#define LG2_YQ 6                  // float4 loads per thread and strip for the masked-out rows
+#define LG2_NKC_MAX 64
+
+#if defined(__HIPCC__)
+#define LG2_DEV __device__ __forceinline__
+// The value is declared modified: address arithmetic derived from it stays inside the loop
+// instead of being hoisted into dozens of long-lived (and then spilled) registers.
+#define LG2_OPAQUE(v) asm volatile("" : "+v"(v))
+// The instruction scheduler does not move anything across this point: the two transforms of a
+// pipeline stage run one after the other instead of interleaved, which is what keeps their
+// temporaries (and with them the kernel) within the register file.
+#define LG2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LG2_FENCE()
+#define LG2_DEV inline
+#define LG2_OPAQUE(v) asm volatile("" : "+r"(v))
+struct float4 { float x, y, z, w; };
+#endif
+
+// element at byte offset `off` (32 bit, unsigned) from a workgroup-uniform base: on the GPU
+// this is the scalar-base + vector-offset form of global_load / global_store
+LG2_DEV float lg2_ld(const float* base, unsigned off) { return *(const float*)((const char*)base + off); }
+LG2_DEV void lg2_st(float* base, unsigned off, float v) { *(float*)((char*)base + off) = v; }
+
+struct Lg2Lds {
+    cf32* tw;      // [192]   (cos, sin)(2 pi m / 192)
+    cf32* S;       // [192][32] pass A -> pass B exchange of one strip
+    cf32* Rk;      // [nkc][208] kept k_y rows
+    int* rowpos;   // [192] position of a k_y row in the kept-row list, -1 if masked out
+    int* rowl;     // [192] the kept-row list
+    int* unrow;    // [192] the masked-out rows, ascending
+    float* red;    // [512] loss reduction
+};
+
+FFT_HD size_t lg2_lds_bytes(int nkc) {
+    return (size_t)(LG2_R + LG2_R * LG2_SW + (size_t)nkc * LG2_RS) * sizeof(cf32) +
+           3 * LG2_R * sizeof(int) + LG2_THREADS * sizeof(float);
+}
+
+FFT_HD Lg2Lds lg2_carve(float* lds, int nkc) {
+    Lg2Lds L;
+    L.tw = (cf32*)lds;
+    L.S = L.tw + LG2_R;
+    L.Rk = L.S + LG2_R * LG2_SW;
+    L.rowpos = (int*)(L.Rk + (size_t)nkc * LG2_RS);
+    L.rowl = L.rowpos + LG2_R;
+    L.unrow = L.rowl + LG2_R;
+    L.red = (float*)(L.unrow + LG2_R);
+    return L;
+}
+
+// slot n of a row (natural order) -> position in the padded row
+FFT_HD int lg2_phys(int n) { return n + (int)((unsigned)n / 12u); }
+FFT_HD float lg2_sgn(int k) { return (k & 1) ? -1.f : 1.f; }
+
+// pass-A inputs for task (bb, col): image rows 12 a + bb; off = byte offset of (row bb, column)
+LG2_DEV void lg2_load_strip(const float* xr, const float* xi, unsigned off, cf32 (&v)[16]) {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const unsigned o = off + (unsigned)a * (12u * LG2_R * 4u);
+        v[a] = c_make(lg2_ld(xr, o), lg2_ld(xi, o));
+    }
+}
+
+// Tables of one mask frame.  The caller syncs before (LDS reuse) -- this function ends synced.
+template <class Ctx>
+LG2_DEV void lg2_tables(const Ctx& ctx, const Lg2Lds& L, const int* rowlist, int nk) {
+    const int tid = ctx.tid();
+    for (int e = tid; e < LG2_R; e += LG2_THREADS) {
+        L.tw[e] = ctx.cos_sin_2pi_over_192(e);
+        L.rowpos[e] = -1;
+    }
+    ctx.sync();
+    for (int e = tid; e < nk; e += LG2_THREADS) {
+        const int r = rowlist[e];
+        L.rowpos[r] = e;
+        L.rowl[e] = r;
+    }
+    ctx.sync();
+    ctx.rank_unkept(L.rowpos, L.unrow, L.red);      // unrow[rank] = row, ascending; ends synced
+}
+
+template <class Ctx>
+LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
+    const int tid = ctx.tid();
+    red[tid] = v;
+    ctx.sync();
+    if (tid < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LG2_THREADS / 64; ++k) s += red[tid + 64 * k];
+        red[tid] = s;
+    }
+    ctx.sync();
+    float t = 0.f;
+    if (tid == 0)
+        for (int k = 0; k < 64; ++k) t += red[k];
+    return t;                                        // valid in thread 0
+}
+
+// One workgroup per frame (frame = block index).  x, grad: [nframes][2][R][R];
+// y: [y_batch*T][2][R][R]; rows [mask_frames][R], nrows [mask_frames]; every mask frame has at
+// most nkc <= 64 kept rows (the caller checked).  grad may be null (loss only).
+template <class Ctx>
+LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* __restrict__ y,
+                      int y_batch, const int* __restrict__ rows, const int* __restrict__ nrows,
+                      int mask_frames, int T, int nframes, int nkc,
+                      const float* __restrict__ chain_scale, float* __restrict__ loss_part,
+                      float* __restrict__ grad) {
+    constexpr int R = LG2_R, SW = LG2_SW, NS = LG2_NS, RS = LG2_RS, Q = LG2_R / 4;
+    const Lg2Lds L = lg2_carve(ctx.lds(), nkc);
+    const int tid = ctx.tid();
+    const size_t fsz = (size_t)2 * R * R;
+    // thread roles in the column passes: column col of the strip; pass A task bb = g (12 per
+    // column, waves 6 and 7 have none), pass B task c = g (16 per column).  Each phase derives
+    // them again from an opaque copy of the thread id, so that its address arithmetic is not
+    // hoisted out of the frame loop into long-lived registers.
+#define LG2_IDS(t_)                                                                    \
+    int t_ = tid;                                                                      \
+    LG2_OPAQUE(t_);                                                                    \
+    const int col = t_ & 31, g = t_ >> 5;                                              \
+    const bool a_task = g < 12;                                                        \
+    const int bb = a_task ? g : 0;                                                     \
+    const unsigned offA = (unsigned)(bb * R + col) * 4u; /* (row bb, column col), strip 0 */ \
+    const unsigned offB = (unsigned)(g * R + col) * 4u;  /* (row g, column col) */     \
+    (void)offA; (void)offB;
+
+    const int frame = ctx.block();
+    if (frame >= nframes) return;
+    cf32 an[16];                                     // pass-A inputs, one strip ahead
+    {
+        LG2_IDS(t0)
+        if (a_task) lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA, an);
+    }
+
+    // per-thread constants of a mask frame: the row-buffer
+    // positions (one byte each, 0xff = masked out) of this thread's pass-B outputs ky = g + 16 d
+    // and inverse pass-A inputs ky = 12 a + bb
+    int nk = 0, n_un = R;
+    unsigned rpB[3], rpA[4];
+#define LG2_RP(tab, i) ((int)(signed char)((tab)[(i) >> 2] >> (8 * ((i) & 3))))
+
+    {
+        const int b = frame / T, t = frame - b * T;
+        const int mf = mask_frames == 1 ? 0 : t;
+        {
+            nk = nrows[mf];
+            n_un = R - nk;
+            lg2_tables(ctx, L, rows + (size_t)mf * R, nk);
+            LG2_IDS(t1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rpA[i] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rpA[i] |= (unsigned)((a_task ? L.rowpos[12 * (4 * i + k) + bb] : -1) & 0xff) << (8 * k);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                rpB[i] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rpB[i] |= (unsigned)(L.rowpos[g + 16 * (4 * i + k)] & 0xff) << (8 * k);
+            }
+        }
+        const float* xr = x + (size_t)frame * fsz;
+        const float* xi = xr + R * R;
+        const float* yr = y + ((size_t)(y_batch > 1 ? b : 0) * T + t) * fsz;
+        const float* yi = yr + R * R;
+        const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
+        float acc = 0.f;
+        ctx.tick(0, frame);
+
+        // ---------------------------------------------------------------- forward column phase
+        {
+        LG2_IDS(t2)
+        const float sgB = lg2_sgn(g);                // (-1)^ky for ky = g + 16 d
+        cf32 a[16], u[12];
+        float4 yq[LG2_YQ];
+        int ytotal = 0;                              // float4 of the chunk held in yq
+#pragma unroll 1
+        for (int s = 0; s < NS; ++s) {
+            if (a_task) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = an[i];
+                unsigned o = offA + (unsigned)(s + 1) * (SW * 4u);
+                LG2_OPAQUE(o);
+                if (s + 1 < NS) lg2_load_strip(xr, xi, o, an);
+            }
+            // masked-out rows carry the residual -y: their |y|^2, a sixth of the rows per strip,
+            // loaded one strip ahead of its use
+#pragma unroll
+            for (int i = 0; i < LG2_YQ; ++i)
+                if (tid + i * LG2_THREADS < ytotal)
+                    acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
+            {
+                const int q0 = s * n_un / NS;
+                ytotal = ((s + 1) * n_un / NS - q0) * (2 * Q);          // both planes
+                if (ytotal > 0) {
+#pragma unroll
+                    for (int i = 0; i < LG2_YQ; ++i) {
+                        int e = tid + i * LG2_THREADS;
+                        e = e < ytotal ? e : ytotal - 1;
+                        const int q = e / (2 * Q), r = e - q * (2 * Q);     // r: plane * Q + c4
+                        const int pl = r >= Q;
+                        const unsigned o = (unsigned)(pl * R * R + L.unrow[q0 + q] * R + 4 * (r - pl * Q)) * 4u;
+                        yq[i] = *(const float4*)((const char*)yr + o);
+                    }
+                }
+            }
+            LG2_FENCE();
+            if (s > 0) {                             // pass B of strip s-1, kept rows -> Rk
+                fft192_pass_b<-1>(u);
+                const int n = lg2_phys((s - 1) * SW + col);
+                unsigned rq[3] = {rpB[0], rpB[1], rpB[2]};
+                LG2_OPAQUE(rq[0]); LG2_OPAQUE(rq[1]); LG2_OPAQUE(rq[2]);
+#pragma unroll
+                for (int d = 0; d < 12; ++d) {
+                    const int j = LG2_RP(rq, d);
+                    if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y);
+                }
+            }
+            LG2_FENCE();
+            if (a_task) {                            // pass A of strip s
+                fft16<-1>(a);
+#pragma unroll
+                for (int c = 1; c < 16; ++c) {
+                    const cf32 w = L.tw[bb * c];
+                    a[c] = c_rot<-1>(a[c], w.x, w.y);
+                }
+            }
+            ctx.sync();
+            if (a_task) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = a[c];
+            }
+            ctx.sync();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col];
+        }
+        ctx.tick(1, frame);
+#pragma unroll
+        for (int i = 0; i < LG2_YQ; ++i)
+            if (tid + i * LG2_THREADS < ytotal)
+                acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
+        {
+            fft192_pass_b<-1>(u);
+            const int n = lg2_phys((NS - 1) * SW + col);
+#pragma unroll
+            for (int d = 0; d < 12; ++d) {
+                const int j = LG2_RP(rpB, d);
+                if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y);
+            }
+        }
+        }
+        // measurement rows of this thread's pass-B tasks (row j, group c): kx = c + 16 d; the
+        // first round's are fetched here, the second round's under the first round's transform
+        float ya[12], yb[12], yc[12], yd[12];
+        int tr = tid;
+        LG2_OPAQUE(tr);
+        const int c16 = tr & 15, j0 = tr >> 4, j1 = (tr + LG2_THREADS) >> 4;
+#define LG2_YLOAD(j_, re_, im_)                                                        \
+        if ((j_) < nk) {                                                               \
+            const unsigned o_ = (unsigned)(rows[(size_t)mf * R + (j_)] * R + c16) * 4u; \
+            _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
+                re_[d] = lg2_ld(yr, o_ + 64u * d);                                     \
+                im_[d] = lg2_ld(yi, o_ + 64u * d);                                     \
+            }                                                                          \
+        }
+        LG2_YLOAD(j0, ya, yb)
+        ctx.sync();                                  // Rk complete
+        ctx.tick(2, frame);
+
+        // ---------------------------------------------------------------- row phase
+        // pass A (forward along x): task (row j, bb), 16 lanes per row of which 12 work
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const int j = r ? j1 : j0;
+            if (j < nk && c16 < 12) {
+                cf32* row = L.Rk + j * RS + c16;
+                cf32 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
+                fft192_pass_a<-1>(v, c16, L.tw);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
+            }
+        }
+        ctx.sync();
+        ctx.tick(3, frame);
+        // pass B + residual + loss + first pass of the inverse (12-point over d, twiddle q c)
+#define LG2_ROW_B(j_, re_, im_)                                                        \
+        if ((j_) < nk) {                                                               \
+            cf32* row = L.Rk + (j_) * RS + 13 * c16;                                   \
+            cf32 v[12];                                                                \
+            _Pragma("unroll") for (int i = 0; i < 12; ++i) v[i] = row[i];              \
+            fft192_pass_b<-1>(v);            /* v[d] = (-1)^ky FFT2(z)[ky][c + 16 d] */ \
+            const float sx = lg2_sgn(c16), sc = cs2 * sx * lg2_sgn(L.rowl[j_]);        \
+            _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
+                const float rr = sx * v[d].x - re_[d], ri = sx * v[d].y - im_[d];      \
+                acc += rr * rr + ri * ri;                                              \
+                v[d] = c_make(sc * rr, sc * ri);                                       \
+            }                                                                          \
+            if (grad) {                                                                \
+                fft12<1>(v);                                                           \
+                _Pragma("unroll") for (int q = 1; q < 12; ++q) {                       \
+                    const cf32 w = L.tw[q * c16];                                      \
+                    v[q] = c_rot<1>(v[q], w.x, w.y);                                   \
+                }                                                                      \
+                _Pragma("unroll") for (int i = 0; i < 12; ++i) row[i] = v[i];          \
+            }                                                                          \
+        }
+        LG2_YLOAD(j1, yc, yd)
+        LG2_FENCE();
+        LG2_ROW_B(j0, ya, yb)
+        LG2_FENCE();
+        LG2_ROW_B(j1, yc, yd)
+#undef LG2_ROW_B
+#undef LG2_YLOAD
+        if (grad) {
+            ctx.sync();
+            ctx.tick(4, frame);
+            // second pass of the inverse: task (row j, q), 16-point over c -> n = q + 12 p
+#pragma unroll 1
+            for (int r = 0; r < 2; ++r) {
+                const int j = r ? j1 : j0;
+                if (j < nk && c16 < 12) {
+                    cf32* row = L.Rk + j * RS + c16;
+                    cf32 v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
+                    fft16<1>(v);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
+                }
+            }
+            ctx.sync();
+            ctx.tick(5, frame);
+
+            // ------------------------------------------------------------ inverse column phase
+            float* dr = grad + (size_t)frame * fsz;
+            float* di = dr + R * R;
+            LG2_IDS(t3)
+            cf32 a[16], u[12];
+#define LG2_INV_A(strip)                                                              \
+            if (a_task) {                                                             \
+                const int n_ = lg2_phys((strip) * SW + col);                          \
+                unsigned rq_[4] = {rpA[0], rpA[1], rpA[2], rpA[3]};                   \
+                LG2_OPAQUE(rq_[0]); LG2_OPAQUE(rq_[1]); LG2_OPAQUE(rq_[2]); LG2_OPAQUE(rq_[3]); \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) {                      \
+                    const int j_ = LG2_RP(rq_, i);                                    \
+                    a[i] = j_ >= 0 ? L.Rk[j_ * RS + n_] : c_make(0.f, 0.f);           \
+                }                                                                     \
+                fft16<1>(a);                                                          \
+                _Pragma("unroll") for (int c = 1; c < 16; ++c) {                      \
+                    const cf32 w_ = L.tw[bb * c];                                     \
+                    a[c] = c_rot<1>(a[c], w_.x, w_.y);                                \
+                }                                                                     \
+            }
+            LG2_INV_A(0)
+            if (a_task) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = a[c];
+            }
+            ctx.sync();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col];
+#pragma unroll 1
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) { LG2_INV_A(s + 1) }
+                LG2_FENCE();
+                fft192_pass_b<1>(u);
+                unsigned ob = offB + (unsigned)s * (SW * 4u);
+                LG2_OPAQUE(ob);
+#pragma unroll
+                for (int d = 0; d < 12; ++d) {
+                    const unsigned o = ob + (unsigned)d * (16u * R * 4u);
+                    lg2_st(dr, o, u[d].x);
+                    lg2_st(di, o, u[d].y);
+                }
+                if (s + 1 < NS) {
+                    ctx.sync();
+                    if (a_task) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = a[c];
+                    }
+                    ctx.sync();
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col];
+                }
+            }
+#undef LG2_INV_A
+        }
+        ctx.tick(6, frame);
+        const float tot = lg2_block_sum(ctx, acc, L.red);
+        if (tid == 0) loss_part[frame] = tot;
+        ctx.tick(7, frame);
+    }
+#undef LG2_RP
+#undef LG2_IDS
+}
