@@ -207,7 +207,8 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
 /* loss[b] = sum |A(x) - y|^2 over every k-space entry (base.py:40-41);
  * grad = chain_scale[b] * d loss[b] / d x  (autograd of the above; Appendix B "MRI").
  * grad may be NULL (loss only).  chain_scale may be NULL (=1).
- * loss_part: workspace float[B*T] (per-frame partial losses); loss [B]. */
+ * loss_part: workspace float[2*B*T] (per-frame partial losses, then shares of the masked-out
+ * rows' sum |y|^2 of a batch-1 measurement); loss [B]. */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
                   const float* chain_scale, float* loss_part, float* loss, float* grad,

@@ -8,10 +8,10 @@ from step_amd.forward_operator import get_operator
 dev = 'cuda:0'
 tag = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else 'libstep_amd.so'
 tag += ' v' + os.environ.get('STEP_MRI_KERNEL', '2')
-for mode in ("same_mask", "split_mask"):
+for mode, yb in (("same_mask", 1), ("split_mask", 1), ("same_mask", 0)):
     op = get_operator("mri", acc_factor=6, mode=mode, resolution=192, frames=12, num_acs_lines=24)
     for B in (32, 64, 256):
-        x = torch.randn(B, 12, 2, 192, 192, device=dev); y = op(torch.randn(1, 12, 2, 192, 192, device=dev))
+        x = torch.randn(B, 12, 2, 192, 192, device=dev); y = op(torch.randn(yb or B, 12, 2, 192, 192, device=dev))
         for _ in range(3): op.gradient(x, y)
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
@@ -19,4 +19,4 @@ for mode in ("same_mask", "split_mask"):
             a.record(); op.gradient(x, y); b.record()
         torch.cuda.synchronize()
         ts = sorted(a.elapsed_time(b) for a, b in ev); m = ts[len(ts)//2]
-        print('%-22s %-10s B=%3d  %.3f ms  %.0f GB/s algorithmic' % (tag, mode, B, m, 24*12*192*192*B/m/1e6), flush=True)
+        print('%-22s %-10s y_batch=%-3d B=%3d  %.3f ms  %.0f GB/s algorithmic' % (tag, mode, yb or B, B, m, 24*12*192*192*B/m/1e6), flush=True)

@@ -348,6 +348,11 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         exi[q] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
     }
     float gr[16], gi[16], gfl;
+#ifdef EXP3_NT_STORE
+#define S3_STG(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#else
+#define S3_STG(ptr, v) (*(ptr) = (v))
+#endif
 #define S3_GLOAD(b)                                                                          \
     {                                                                                        \
         const float2* gp_ = (const float2*)gvis + ((size_t)(b) * T + t) * F;                 \
@@ -403,12 +408,13 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int y = ytop + (r & 3) + 8 * (r >> 2);
-                gf[y * W] = ev[r] + od[r];
-                gf[(H - 1 - y) * W] = ev[r] - od[r];
+                S3_STG(gf + y * W, ev[r] + od[r]);
+                S3_STG(gf + (H - 1 - y) * W, ev[r] - od[r]);
             }
         }
     }
 #undef S3_GLOAD
+#undef S3_STG
 }
 
 template <int H, int W>

@@ -409,33 +409,18 @@ struct Lg2DevCtx {
         sincospif((float)e * (1.0f / 96.0f), &sn, &cn);
         return c_make(cn, sn);
     }
-    // rank of every masked-out row among the masked-out rows: ballot + popcount within each of
-    // the three waves that cover the 192 rows, wave totals through LDS (red[0..2])
-    __device__ __forceinline__ void rank_unkept(const int* rowpos, int* unrow, float* red) const {
-        const int e = threadIdx.x;
-        const bool out_row = e < MRI_R && rowpos[e] < 0;
-        const unsigned long long m = __ballot(out_row);
-        const int below = __popcll(m & ((1ull << (e & 63)) - 1ull));
-        if (e < MRI_R && (e & 63) == 0) red[e >> 6] = (float)__popcll(m);
-        __syncthreads();
-        if (out_row) {
-            int base = 0;
-            for (int w = 0; w < (e >> 6); ++w) base += (int)red[w];
-            unrow[base + below] = e;
-        }
-        __syncthreads();
-    }
 };
 
+template <bool YQ>
 __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2(
     const float* __restrict__ x, const float* __restrict__ y, int y_batch,
     const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T,
     int nframes, int nkc, const float* __restrict__ chain_scale, float* __restrict__ loss_part,
-    float* __restrict__ grad) {
+    float* __restrict__ unk_part, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Lg2DevCtx ctx{lds};
-    lg2_body(ctx, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part,
-             grad);
+    lg2_body<YQ>(ctx, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
+                 loss_part, unk_part, grad);
 }
 
 // STEP_MRI_KERNEL=1 pins the first-generation kernel (experiments, cross-checks in the tests)
@@ -479,13 +464,18 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
     }
 }
 
-__global__ void k_mri_loss_finish(const float* __restrict__ part, int B, int T,
-                                  float* __restrict__ loss) {
+// loss[b] = sum_t part[b][t] + sum of unk[0 .. n_unk): the shares of the masked-out rows' |y|^2
+// of a batch-1 measurement, which the pipelined kernel sums once for all chains (n_unk = 0
+// when the partial losses already hold them)
+__global__ void k_mri_loss_finish(const float* __restrict__ part, const float* __restrict__ unk,
+                                  int n_unk, int B, int T, float* __restrict__ loss) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float s = 0.f;
     for (int t = 0; t < T; ++t) s += part[(size_t)b * T + t];
-    loss[b] = s;
+    float su = 0.f;
+    for (int i = 0; i < n_unk; ++i) su += unk[i];
+    loss[b] = s + su;
 }
 
 static int mri_check(const char* who, int B, int T, int R, const int32_t* rows,
@@ -541,14 +531,24 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
     if (int rc = mri_check("mri_loss_grad", B, T, R, rows, nrows, mask_frames)) return rc;
     const int nkc = pick_nkc(max_rows);
     hipStream_t s = (hipStream_t)stream;
+    float* unk = loss_part + (size_t)B * T;              // second part of the workspace
+    int n_unk = 0;
     if (max_rows <= LG2_NKC_MAX && mri_variant() == 2) {
         // every mask frame fits one row buffer: pipelined kernel
         const size_t lds = lg2_lds_bytes(nkc);
         const int nframes = B * T;
-        step_allow_lds((const void*)k_mri_loss_grad2, lds);
-        hipLaunchKernelGGL(k_mri_loss_grad2, dim3(nframes), dim3(LG2_THREADS),
-                           lds, s, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc,
-                           chain_scale, loss_part, grad);
+        if (y_batch == 1) {
+            n_unk = (B < LG2_UNK_PARTS ? B : LG2_UNK_PARTS) * T;
+            step_allow_lds((const void*)k_mri_loss_grad2<false>, lds);
+            hipLaunchKernelGGL(k_mri_loss_grad2<false>, dim3(nframes), dim3(LG2_THREADS), lds, s, x, y,
+                               y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
+                               loss_part, unk, grad);
+        } else {
+            step_allow_lds((const void*)k_mri_loss_grad2<true>, lds);
+            hipLaunchKernelGGL(k_mri_loss_grad2<true>, dim3(nframes), dim3(LG2_THREADS), lds, s, x, y,
+                               y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
+                               loss_part, unk, grad);
+        }
     } else {
         const size_t lds = mri_lds_bytes(nkc);
         step_allow_lds((const void*)k_mri_loss_grad, lds);
@@ -556,7 +556,7 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
                            rows, nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
     }
     STEP_CHECK_LAUNCH("mri_loss_grad");
-    hipLaunchKernelGGL(k_mri_loss_finish, dim3((B + 255) / 256), dim3(256), 0, s, loss_part, B, T, loss);
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3((B + 255) / 256), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss);
     STEP_CHECK_LAUNCH("mri_loss_finish");
     return STEP_OK;
 }

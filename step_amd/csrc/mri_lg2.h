@@ -15,6 +15,11 @@
 //     k = c + 16 d -> n = q + 12 p), then the inverse's 16-point pass;
 //   * row buffer padded 12 -> 13 per group (stride 208): both row-pass access patterns are
 //     conflict-free;
+//   * the masked-out k_y rows, where A(x) = 0 and the residual is -y, contribute sum |y|^2 to the
+//     loss: a constant of the measurement.  With one measurement for all chains (y_batch = 1,
+//     YQ = false) the workgroups of the first 16 chains each sum a 16th of those rows once --
+//     a quarter less traffic per chain; with a measurement per chain (YQ = true) every
+//     workgroup sums its own, 32 rows per strip, loaded one strip ahead of their use;
 //   * one workgroup per frame (a loop over frames inside the kernel carries the prefetched
 //     strip around the back edge and the register allocator then spills ~170 values, whose
 //     reloads wait behind every store in flight -- measured 1.5x slower than no loop).
@@ -28,8 +33,9 @@
 #define LG2_NS 6                  // strips per frame
 #define LG2_THREADS 512
 #define LG2_RS 208                // row-buffer stride in cf32: 16 groups of 12, each padded to 13
-#define LG2_YQ 6                  // float4 loads per thread and strip for the masked-out rows
 #define LG2_NKC_MAX 64
+#define LG2_YQ 6                  // float4 loads per thread and strip for the masked-out rows
+#define LG2_UNK_PARTS 16          // a batch-1 measurement: its masked-out rows are shared out
 
 #if defined(__HIPCC__)
 #define LG2_DEV __device__ __forceinline__
@@ -58,13 +64,12 @@ struct Lg2Lds {
     cf32* Rk;      // [nkc][208] kept k_y rows
     int* rowpos;   // [192] position of a k_y row in the kept-row list, -1 if masked out
     int* rowl;     // [192] the kept-row list
-    int* unrow;    // [192] the masked-out rows, ascending
     float* red;    // [512] loss reduction
 };
 
 FFT_HD size_t lg2_lds_bytes(int nkc) {
     return (size_t)(LG2_R + LG2_R * LG2_SW + (size_t)nkc * LG2_RS) * sizeof(cf32) +
-           3 * LG2_R * sizeof(int) + LG2_THREADS * sizeof(float);
+           2 * LG2_R * sizeof(int) + LG2_THREADS * sizeof(float);
 }
 
 FFT_HD Lg2Lds lg2_carve(float* lds, int nkc) {
@@ -74,8 +79,7 @@ FFT_HD Lg2Lds lg2_carve(float* lds, int nkc) {
     L.Rk = L.S + LG2_R * LG2_SW;
     L.rowpos = (int*)(L.Rk + (size_t)nkc * LG2_RS);
     L.rowl = L.rowpos + LG2_R;
-    L.unrow = L.rowl + LG2_R;
-    L.red = (float*)(L.unrow + LG2_R);
+    L.red = (float*)(L.rowl + LG2_R);
     return L;
 }
 
@@ -107,7 +111,6 @@ LG2_DEV void lg2_tables(const Ctx& ctx, const Lg2Lds& L, const int* rowlist, int
         L.rowl[e] = r;
     }
     ctx.sync();
-    ctx.rank_unkept(L.rowpos, L.unrow, L.red);      // unrow[rank] = row, ascending; ends synced
 }
 
 template <class Ctx>
@@ -131,12 +134,15 @@ LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
 // One workgroup per frame (frame = block index).  x, grad: [nframes][2][R][R];
 // y: [y_batch*T][2][R][R]; rows [mask_frames][R], nrows [mask_frames]; every mask frame has at
 // most nkc <= 64 kept rows (the caller checked).  grad may be null (loss only).
-template <class Ctx>
+// YQ: loss_part[frame] = sum |A(x) - y|^2 over all rows.  !YQ (y_batch == 1): loss_part[frame]
+// covers the kept rows, and unk_part[b * T + t], b < min(B, 16), the b-th share of the masked-out
+// rows of measurement frame t (every chain's loss gets all shares: the caller adds them up).
+template <bool YQ, class Ctx>
 LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* __restrict__ y,
                       int y_batch, const int* __restrict__ rows, const int* __restrict__ nrows,
                       int mask_frames, int T, int nframes, int nkc,
                       const float* __restrict__ chain_scale, float* __restrict__ loss_part,
-                      float* __restrict__ grad) {
+                      float* __restrict__ unk_part, float* __restrict__ grad) {
     constexpr int R = LG2_R, SW = LG2_SW, NS = LG2_NS, RS = LG2_RS, Q = LG2_R / 4;
     const Lg2Lds L = lg2_carve(ctx.lds(), nkc);
     const int tid = ctx.tid();
@@ -157,16 +163,20 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
 
     const int frame = ctx.block();
     if (frame >= nframes) return;
-    cf32 an[16];                                     // pass-A inputs, one strip ahead
+    cf32 an[16], an2[16];                            // pass-A inputs, one and two strips ahead
     {
         LG2_IDS(t0)
-        if (a_task) lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA, an);
+        if (a_task) {
+            lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA, an);
+            if (!YQ)     // registers allow the second strip only without the measurement prefetch
+                lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA + SW * 4u, an2);
+        }
     }
 
     // per-thread constants of a mask frame: the row-buffer
     // positions (one byte each, 0xff = masked out) of this thread's pass-B outputs ky = g + 16 d
     // and inverse pass-A inputs ky = 12 a + bb
-    int nk = 0, n_un = R;
+    int nk = 0;
     unsigned rpB[3], rpA[4];
 #define LG2_RP(tab, i) ((int)(signed char)((tab)[(i) >> 2] >> (8 * ((i) & 3))))
 
@@ -175,7 +185,6 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         const int mf = mask_frames == 1 ? 0 : t;
         {
             nk = nrows[mf];
-            n_un = R - nk;
             lg2_tables(ctx, L, rows + (size_t)mf * R, nk);
             LG2_IDS(t1)
 #pragma unroll
@@ -198,7 +207,20 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         const float* yr = y + ((size_t)(y_batch > 1 ? b : 0) * T + t) * fsz;
         const float* yi = yr + R * R;
         const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
-        float acc = 0.f;
+        float acc = 0.f, acc_u = 0.f;
+        const int nparts = nframes / T < LG2_UNK_PARTS ? nframes / T : LG2_UNK_PARTS;
+        const bool has_share = !YQ && b < nparts;        // uniform over the workgroup
+        if (has_share) {
+            const int r0 = b * R / nparts, r1 = (b + 1) * R / nparts;
+#pragma unroll 4
+            for (int e = tid; e < (r1 - r0) * 2 * Q; e += LG2_THREADS) {
+                const int row = r0 + e / (2 * Q), r = e % (2 * Q), pl = r >= Q;
+                if (L.rowpos[row] < 0) {
+                    const float4 v = *(const float4*)(yr + (size_t)pl * R * R + row * R + 4 * (r - pl * Q));
+                    acc_u += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            }
+        }
         ctx.tick(0, frame);
 
         // ---------------------------------------------------------------- forward column phase
@@ -207,35 +229,39 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         const float sgB = lg2_sgn(g);                // (-1)^ky for ky = g + 16 d
         cf32 a[16], u[12];
         float4 yq[LG2_YQ];
-        int ytotal = 0;                              // float4 of the chunk held in yq
+        if (YQ) {
+#pragma unroll
+            for (int i = 0; i < LG2_YQ; ++i) yq[i].x = yq[i].y = yq[i].z = yq[i].w = 0.f;
+        }
 #pragma unroll 1
         for (int s = 0; s < NS; ++s) {
             if (a_task) {
+                if (!YQ) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] = an[i];
-                unsigned o = offA + (unsigned)(s + 1) * (SW * 4u);
-                LG2_OPAQUE(o);
-                if (s + 1 < NS) lg2_load_strip(xr, xi, o, an);
+                    for (int i = 0; i < 16; ++i) { a[i] = an[i]; an[i] = an2[i]; }
+                    unsigned o = offA + (unsigned)(s + 2) * (SW * 4u);
+                    LG2_OPAQUE(o);
+                    if (s + 2 < NS) lg2_load_strip(xr, xi, o, an2);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a[i] = an[i];
+                    unsigned o = offA + (unsigned)(s + 1) * (SW * 4u);
+                    LG2_OPAQUE(o);
+                    if (s + 1 < NS) lg2_load_strip(xr, xi, o, an);
+                }
             }
-            // masked-out rows carry the residual -y: their |y|^2, a sixth of the rows per strip,
-            // loaded one strip ahead of its use
+            if (YQ) {
+                // masked-out rows 32 s .. 32 s + 31 of the measurement (both planes), fetched a
+                // strip ahead of their use; kept rows stay zero here (the row phase has them)
 #pragma unroll
-            for (int i = 0; i < LG2_YQ; ++i)
-                if (tid + i * LG2_THREADS < ytotal)
+                for (int i = 0; i < LG2_YQ; ++i) {
                     acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
-            {
-                const int q0 = s * n_un / NS;
-                ytotal = ((s + 1) * n_un / NS - q0) * (2 * Q);          // both planes
-                if (ytotal > 0) {
-#pragma unroll
-                    for (int i = 0; i < LG2_YQ; ++i) {
-                        int e = tid + i * LG2_THREADS;
-                        e = e < ytotal ? e : ytotal - 1;
-                        const int q = e / (2 * Q), r = e - q * (2 * Q);     // r: plane * Q + c4
-                        const int pl = r >= Q;
-                        const unsigned o = (unsigned)(pl * R * R + L.unrow[q0 + q] * R + 4 * (r - pl * Q)) * 4u;
-                        yq[i] = *(const float4*)((const char*)yr + o);
-                    }
+                    const int e = tid + i * LG2_THREADS;             // < 32 rows * 2 planes * Q
+                    const int row = 32 * s + e / (2 * Q), r = e % (2 * Q), pl = r >= Q;
+                    yq[i].x = yq[i].y = yq[i].z = yq[i].w = 0.f;
+                    if (L.rowpos[row] < 0)
+                        yq[i] = *(const float4*)((const char*)yr +
+                                                 (unsigned)(pl * R * R + row * R + 4 * (r - pl * Q)) * 4u);
                 }
             }
             LG2_FENCE();
@@ -269,10 +295,11 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col];
         }
         ctx.tick(1, frame);
+        if (YQ) {
 #pragma unroll
-        for (int i = 0; i < LG2_YQ; ++i)
-            if (tid + i * LG2_THREADS < ytotal)
+            for (int i = 0; i < LG2_YQ; ++i)
                 acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
+        }
         {
             fft192_pass_b<-1>(u);
             const int n = lg2_phys((NS - 1) * SW + col);
@@ -424,6 +451,11 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         ctx.tick(6, frame);
         const float tot = lg2_block_sum(ctx, acc, L.red);
         if (tid == 0) loss_part[frame] = tot;
+        if (has_share) {
+            ctx.sync();
+            const float tot_u = lg2_block_sum(ctx, acc_u, L.red);
+            if (tid == 0) unk_part[frame] = tot_u;
+        }
         ctx.tick(7, frame);
     }
 #undef LG2_RP

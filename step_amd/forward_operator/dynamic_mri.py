@@ -122,7 +122,7 @@ class DynamicMRI(Operator):
             raise ValueError("measurement shape %s does not match input %s"
                              % (tuple(y.shape), tuple(x.shape)))
         rows, nrows = self._tables(x.device)
-        part = torch.empty(B * T, device=x.device, dtype=torch.float32)
+        part = torch.empty(2 * B * T, device=x.device, dtype=torch.float32)
         loss = torch.empty(B, device=x.device, dtype=torch.float32)
         grad = torch.empty_like(x) if need_grad else None
         t0 = None
