@@ -113,7 +113,7 @@ LG2_DEV void lg2_tables(const Ctx& ctx, const Lg2Lds& L, const int* rowlist, int
     ctx.sync();
 }
 
-template <class Ctx>
+template <int NT = LG2_THREADS, class Ctx>
 LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
     const int tid = ctx.tid();
     red[tid] = v;
@@ -121,7 +121,7 @@ LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
     if (tid < 64) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LG2_THREADS / 64; ++k) s += red[tid + 64 * k];
+        for (int k = 0; k < NT / 64; ++k) s += red[tid + 64 * k];
         red[tid] = s;
     }
     ctx.sync();
@@ -129,6 +129,104 @@ LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
     if (tid == 0)
         for (int k = 0; k < 64; ++k) t += red[k];
     return t;                                        // valid in thread 0
+}
+
+// Row phase on the kept rows Rk[nk][208] (slot n of a row at n + n / 12), in place, NT threads:
+// forward pass A (16-point, twiddle), then pass B (12-point) + residual against the measurement
+// rows + loss + the first pass of the inverse in the same registers (the inverse runs the
+// transposed decomposition k = c + 16 d -> n = q + 12 p), then the inverse's 16-point pass.
+// In: Rk[j][kx'] = (-1)^ky * column FFT; out: the adjoint's input rows in natural order.
+// rowlist: the kept rows of this mask frame (global memory); rowl: the same list in LDS.
+// Row j of round r is handled by lanes 16 j .. 16 j + 15 of thread index e = tid + r NT; 2 NT / 16
+// must cover nk.  Ends with the row buffer complete but NOT synced when with_grad is false.
+template <int NT, class Ctx>
+LG2_DEV void lg2_row_phase(const Ctx& ctx, cf32* Rk, const cf32* tw, const int* rowl,
+                           const int* __restrict__ rowlist, int nk, const float* __restrict__ yr,
+                           const float* __restrict__ yi, float cs2, bool with_grad, int frame,
+                           float& acc) {
+    constexpr int R = LG2_R, RS = LG2_RS;
+    // measurement rows of this thread's pass-B tasks (row j, group c): kx = c + 16 d; the
+    // first round's are fetched here, the second round's under the first round's transform
+    float ya[12], yb[12], yc[12], yd[12];
+    int tr = ctx.tid();
+    LG2_OPAQUE(tr);
+    const int c16 = tr & 15, j0 = tr >> 4, j1 = (tr + NT) >> 4;
+#define LG2_YLOAD(j_, re_, im_)                                                        \
+    if ((j_) < nk) {                                                               \
+        const unsigned o_ = (unsigned)(rowlist[(j_)] * R + c16) * 4u; \
+        _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
+            re_[d] = lg2_ld(yr, o_ + 64u * d);                                     \
+            im_[d] = lg2_ld(yi, o_ + 64u * d);                                     \
+        }                                                                          \
+    }
+    LG2_YLOAD(j0, ya, yb)
+    ctx.sync();                                  // Rk complete
+    ctx.tick(2, frame);
+
+    // ---------------------------------------------------------------- row phase
+    // pass A (forward along x): task (row j, bb), 16 lanes per row of which 12 work
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        const int j = r ? j1 : j0;
+        if (j < nk && c16 < 12) {
+            cf32* row = Rk + j * RS + c16;
+            cf32 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
+            fft192_pass_a<-1>(v, c16, tw);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
+        }
+    }
+    ctx.sync();
+    ctx.tick(3, frame);
+    // pass B + residual + loss + first pass of the inverse (12-point over d, twiddle q c)
+#define LG2_ROW_B(j_, re_, im_)                                                        \
+    if ((j_) < nk) {                                                               \
+        cf32* row = Rk + (j_) * RS + 13 * c16;                                   \
+        cf32 v[12];                                                                \
+        _Pragma("unroll") for (int i = 0; i < 12; ++i) v[i] = row[i];              \
+        fft192_pass_b<-1>(v);            /* v[d] = (-1)^ky FFT2(z)[ky][c + 16 d] */ \
+        const float sx = lg2_sgn(c16), sc = cs2 * sx * lg2_sgn(rowl[j_]);        \
+        _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
+            const float rr = sx * v[d].x - re_[d], ri = sx * v[d].y - im_[d];      \
+            acc += rr * rr + ri * ri;                                              \
+            v[d] = c_make(sc * rr, sc * ri);                                       \
+        }                                                                          \
+        if (with_grad) {                                                           \
+            fft12<1>(v);                                                           \
+            _Pragma("unroll") for (int q = 1; q < 12; ++q) {                       \
+                const cf32 w = tw[q * c16];                                      \
+                v[q] = c_rot<1>(v[q], w.x, w.y);                                   \
+            }                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 12; ++i) row[i] = v[i];          \
+        }                                                                          \
+    }
+    LG2_YLOAD(j1, yc, yd)
+    LG2_FENCE();
+    LG2_ROW_B(j0, ya, yb)
+    LG2_FENCE();
+    LG2_ROW_B(j1, yc, yd)
+#undef LG2_ROW_B
+#undef LG2_YLOAD
+    if (with_grad) {
+        ctx.sync();
+        ctx.tick(4, frame);
+        // second pass of the inverse: task (row j, q), 16-point over c -> n = q + 12 p
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const int j = r ? j1 : j0;
+            if (j < nk && c16 < 12) {
+                cf32* row = Rk + j * RS + c16;
+                cf32 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
+                fft16<1>(v);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
+            }
+        }
+    }
 }
 
 // One workgroup per frame (frame = block index).  x, grad: [nframes][2][R][R];
@@ -310,87 +408,9 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             }
         }
         }
-        // measurement rows of this thread's pass-B tasks (row j, group c): kx = c + 16 d; the
-        // first round's are fetched here, the second round's under the first round's transform
-        float ya[12], yb[12], yc[12], yd[12];
-        int tr = tid;
-        LG2_OPAQUE(tr);
-        const int c16 = tr & 15, j0 = tr >> 4, j1 = (tr + LG2_THREADS) >> 4;
-#define LG2_YLOAD(j_, re_, im_)                                                        \
-        if ((j_) < nk) {                                                               \
-            const unsigned o_ = (unsigned)(rows[(size_t)mf * R + (j_)] * R + c16) * 4u; \
-            _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
-                re_[d] = lg2_ld(yr, o_ + 64u * d);                                     \
-                im_[d] = lg2_ld(yi, o_ + 64u * d);                                     \
-            }                                                                          \
-        }
-        LG2_YLOAD(j0, ya, yb)
-        ctx.sync();                                  // Rk complete
-        ctx.tick(2, frame);
-
-        // ---------------------------------------------------------------- row phase
-        // pass A (forward along x): task (row j, bb), 16 lanes per row of which 12 work
-#pragma unroll 1
-        for (int r = 0; r < 2; ++r) {
-            const int j = r ? j1 : j0;
-            if (j < nk && c16 < 12) {
-                cf32* row = L.Rk + j * RS + c16;
-                cf32 v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
-                fft192_pass_a<-1>(v, c16, L.tw);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
-            }
-        }
-        ctx.sync();
-        ctx.tick(3, frame);
-        // pass B + residual + loss + first pass of the inverse (12-point over d, twiddle q c)
-#define LG2_ROW_B(j_, re_, im_)                                                        \
-        if ((j_) < nk) {                                                               \
-            cf32* row = L.Rk + (j_) * RS + 13 * c16;                                   \
-            cf32 v[12];                                                                \
-            _Pragma("unroll") for (int i = 0; i < 12; ++i) v[i] = row[i];              \
-            fft192_pass_b<-1>(v);            /* v[d] = (-1)^ky FFT2(z)[ky][c + 16 d] */ \
-            const float sx = lg2_sgn(c16), sc = cs2 * sx * lg2_sgn(L.rowl[j_]);        \
-            _Pragma("unroll") for (int d = 0; d < 12; ++d) {                           \
-                const float rr = sx * v[d].x - re_[d], ri = sx * v[d].y - im_[d];      \
-                acc += rr * rr + ri * ri;                                              \
-                v[d] = c_make(sc * rr, sc * ri);                                       \
-            }                                                                          \
-            if (grad) {                                                                \
-                fft12<1>(v);                                                           \
-                _Pragma("unroll") for (int q = 1; q < 12; ++q) {                       \
-                    const cf32 w = L.tw[q * c16];                                      \
-                    v[q] = c_rot<1>(v[q], w.x, w.y);                                   \
-                }                                                                      \
-                _Pragma("unroll") for (int i = 0; i < 12; ++i) row[i] = v[i];          \
-            }                                                                          \
-        }
-        LG2_YLOAD(j1, yc, yd)
-        LG2_FENCE();
-        LG2_ROW_B(j0, ya, yb)
-        LG2_FENCE();
-        LG2_ROW_B(j1, yc, yd)
-#undef LG2_ROW_B
-#undef LG2_YLOAD
+        lg2_row_phase<LG2_THREADS>(ctx, L.Rk, L.tw, L.rowl, rows + (size_t)mf * R, nk, yr, yi, cs2,
+                                   grad != nullptr, frame, acc);
         if (grad) {
-            ctx.sync();
-            ctx.tick(4, frame);
-            // second pass of the inverse: task (row j, q), 16-point over c -> n = q + 12 p
-#pragma unroll 1
-            for (int r = 0; r < 2; ++r) {
-                const int j = r ? j1 : j0;
-                if (j < nk && c16 < 12) {
-                    cf32* row = L.Rk + j * RS + c16;
-                    cf32 v[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = row[13 * i];
-                    fft16<1>(v);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) row[13 * i] = v[i];
-                }
-            }
             ctx.sync();
             ctx.tick(5, frame);
 
