@@ -467,15 +467,27 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
 // loss[b] = sum_t part[b][t] + sum of unk[0 .. n_unk): the shares of the masked-out rows' |y|^2
 // of a batch-1 measurement, which the pipelined kernel sums once for all chains (n_unk = 0
 // when the partial losses already hold them)
-__global__ void k_mri_loss_finish(const float* __restrict__ part, const float* __restrict__ unk,
-                                  int n_unk, int B, int T, float* __restrict__ loss) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += part[(size_t)b * T + t];
-    float su = 0.f;
-    for (int i = 0; i < n_unk; ++i) su += unk[i];
-    loss[b] = s + su;
+__global__ __launch_bounds__(256) void k_mri_loss_finish(const float* __restrict__ part,
+                                                         const float* __restrict__ unk, int n_unk,
+                                                         int B, int T, float* __restrict__ loss) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float v = 0.f;
+    for (int i = tid; i < n_unk; i += 256) v += unk[i];
+    red[tid] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {                      // fixed order: reproducible
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const float su = red[0];
+    for (int b = blockIdx.x * 256 + tid; b < B; b += gridDim.x * 256) {
+        const float* p = part + (size_t)b * T;
+        float s = 0.f;
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) s += p[t];
+        loss[b] = s + su;
+    }
 }
 
 static int mri_check(const char* who, int B, int T, int R, const int32_t* rows,
