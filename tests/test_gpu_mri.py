@@ -116,3 +116,42 @@ def test_rejects_other_resolutions(dev):
     op = get_operator("mri", acc_factor=4, mode="same_mask", resolution=64, frames=5, num_acs_lines=8)
     with pytest.raises(RuntimeError, match="only resolution 192"):
         op(torch.randn(1, 5, 2, 64, 64, device=dev))
+
+
+@pytest.mark.parametrize("mode,acc,acs,frames", [("split_mask", 192, 0, 12),      # one kept row in all: 11 empty frames
+                                                 ("random_split_mask", 48, 0, 12),  # 4 rows over 12 frames
+                                                 ("same_mask", 3, 0, 12),          # 64 rows: a full row buffer
+                                                 ("same_mask", 4, 16, 5)])          # another frame count
+def test_ragged_and_empty_masks(mode, acc, acs, frames, dev):
+    """Mask frames with no kept row at all (loss = |y|^2, gradient 0), with a single row, and with
+    exactly as many rows as the row buffer holds; a shared and a per-chain measurement."""
+    from step_amd.forward_operator import get_operator
+    op = get_operator("mri", acc_factor=acc, mode=mode, resolution=192, frames=frames, num_acs_lines=acs)
+    orc = MRIOracle(acc, mode, 192, frames, acs)
+    assert torch.equal(op.mask, orc.mask)
+    gen = torch.Generator().manual_seed(acc + frames)
+    x = torch.randn(3, frames, 2, 192, 192, generator=gen)
+    for yb in (1, 3):
+        y = orc(torch.randn(yb, frames, 2, 192, 192, generator=gen)) \
+            + 0.1 * torch.randn(yb, frames, 2, 192, 192, generator=gen)
+        g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+        g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+        assert_close(l_got, l_ref, RTOL, "loss")
+        assert_close(g_got, g_ref, RTOL, "gradient")
+        assert_close(op.loss(x.to(dev), y.to(dev)), orc.loss(x, y), RTOL, "per-chain loss")
+    assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
+
+
+def test_fused_step_equals_forward_then_adjoint(dev):
+    """The pipelined loss+gradient kernel against the separate forward and adjoint kernels at the
+    bench size: grad = 2 A^H (A x - y), loss = |A x - y|^2, 64 chains, one measurement."""
+    op = make_op("same_mask")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(64, 12, 2, 192, 192, device=dev, generator=gen)
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)) \
+        + 0.05 * torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)
+    g, lsum = op.gradient(x, y, return_loss=True)
+    r = op(x) - y
+    assert_close(g, 2.0 * op._launch_adjoint(r.contiguous()), RTOL, "gradient vs A^H residual")
+    assert_close(op.loss(x, y), (r.double() ** 2).flatten(1).sum(-1), RTOL, "loss vs forward")
+    assert_close(lsum, (r.double() ** 2).sum(), RTOL, "loss sum")

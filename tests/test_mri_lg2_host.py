@@ -87,3 +87,7 @@ def test_full_row_buffer(emu):
 
 def test_more_chains_than_shares(emu):
     run_case(emu, "same_mask", 6, 24, B=18, T=1, yb=1, seed=3)  # 16 shares, chains 16 and 17 hold none
+
+
+def test_frames_without_kept_rows(emu):
+    run_case(emu, "split_mask", 192, 0, B=2, T=3, yb=1)       # one kept row in all: two empty mask frames
