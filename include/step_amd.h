@@ -230,7 +230,8 @@ typedef struct {
 /* score = -grad*inv_tau2 + (xt - x)*inv_sigma2 + prior  (score_fn daps.py:93-104), then
  * mc_update daps.py:135-144 in place on x (and velocity for hmc).  Sets *nan_flag (int32,
  * device) to 1 if any updated x is NaN (the guard of daps.py:202-203 without a per-step sync
- * unless the host chooses to read it).
+ * unless the host chooses to read it).  hmc with momentum 0: the velocity buffer is neither read
+ * nor written (its old value has weight zero in every step).
  * algo 2: x -= lr * (grad + (x - xt) * inv_sigma2) with xt = x0hat (MCMCSampler.optimize,
  * daps.py:210-223); velocity, prior and eps are not read and may be NULL. */
 int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, const float* prior,
