@@ -3,7 +3,10 @@
 // the per-chain loss of base.py:40-41 and the adjoint (SURVEY Appendix B "MRI") in the same
 // launch, so a step moves 24*R*R bytes per frame: read x, read y, write grad.
 //
-// One workgroup (512 threads) per frame, 192 = 16 x 12 in-register FFT passes over LDS:
+// The Langevin step of the shipped masks runs k_mri_loss_grad2, whose body is mri_lg2.h; this file
+// holds the first-generation kernels -- forward only, adjoint only, and the loss+gradient kernel
+// that takes masks with more kept rows than one row buffer -- plus the C ABI.  Their scheme:
+// one workgroup (512 threads) per frame, 192 = 16 x 12 in-register FFT passes over LDS:
 //   1. per 32-column strip: load x, FFT along y (all 192 rows), keep only the masked k_y rows
 //      (52 of 192 at acc 6 / 24 ACS lines) in an LDS row buffer  -> 80 KB instead of 295 KB
 //   2. FFT along x on the kept rows                               = M * FFT2(x)

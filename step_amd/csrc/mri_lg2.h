@@ -5,11 +5,11 @@
 // Same arithmetic as k_mri_loss_grad (mri_fft.hip) -- 192 = 16 x 12 in-register passes over LDS,
 // pruned to the kept k_y rows, fftshift folded into signs -- but scheduled differently:
 //   * software-pipelined column passes: while a thread transforms pass A of strip s (inputs
-//     loaded from global memory straight into the pass-A register layout, one strip ahead) it
+//     loaded from global memory straight into the pass-A register layout, two strips ahead) it
 //     also finishes pass B of strip s-1 from registers; the strip buffer only carries the
 //     A -> B exchange: two barriers and 28 LDS accesses per thread and strip instead of three
 //     barriers and 83;
-//   * column-pass twiddles and row positions live in registers (constant per thread);
+//   * this thread's row-buffer positions live in registers, one byte each (constant per mask);
 //   * the row phase is three in-place passes: pass A, then pass B + residual + loss + the first
 //     pass of the inverse in the same registers (the inverse runs the transposed decomposition
 //     k = c + 16 d -> n = q + 12 p), then the inverse's 16-point pass;
