@@ -62,22 +62,29 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     const int* cp_ent = a.tab.cp_ent;
     const int* ca_ent = a.tab.ca_ent;
     if (STAGED && gvis) {
+        // only this workgroup's slice of the baselines: pointers [s0, s1] and the entries between
+        // ptr[s0] and ptr[s1], kept at their global positions (the unused part of the LDS image
+        // is never touched)
+        const int s0 = (int)((long long)M * blockIdx.y / gridDim.y), s1 = (int)((long long)M * (blockIdx.y + 1) / gridDim.y);
         int* l_cp_ptr = (int*)(red + 96);
         int* l_ca_ptr = l_cp_ptr + M + 1;
         int* l_cp_ent = l_ca_ptr + M + 1;
         int* l_ca_ent = l_cp_ent + 3 * Kcp;
         if (a.w.w_cp > 0.f) {
-            for (int i = threadIdx.x; i <= M; i += CLL_THREADS) l_cp_ptr[i] = cp_ptr[i];
-            for (int i = threadIdx.x; i < 3 * Kcp; i += CLL_THREADS) l_cp_ent[i] = cp_ent[i];
+            for (int i = s0 + threadIdx.x; i <= s1; i += CLL_THREADS) l_cp_ptr[i] = cp_ptr[i];
+            for (int i = cp_ptr[s0] + threadIdx.x; i < cp_ptr[s1]; i += CLL_THREADS) l_cp_ent[i] = cp_ent[i];
         }
         if (a.w.w_camp > 0.f) {
-            for (int i = threadIdx.x; i <= M; i += CLL_THREADS) l_ca_ptr[i] = ca_ptr[i];
-            for (int i = threadIdx.x; i < 4 * Kca; i += CLL_THREADS) l_ca_ent[i] = ca_ent[i];
+            for (int i = s0 + threadIdx.x; i <= s1; i += CLL_THREADS) l_ca_ptr[i] = ca_ptr[i];
+            for (int i = ca_ptr[s0] + threadIdx.x; i < ca_ptr[s1]; i += CLL_THREADS) l_ca_ent[i] = ca_ent[i];
         }
         cp_ptr = l_cp_ptr; ca_ptr = l_ca_ptr; cp_ent = l_cp_ent; ca_ent = l_ca_ent;
     }
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
+    // gridDim.y workgroups share a chain: every one of them evaluates the chi^2 sums (they need
+    // all closure quantities), each takes a slice [m0, m1) of the baselines in the backward gather
+    const int m0 = (int)((long long)M * blockIdx.y / gridDim.y), m1 = (int)((long long)M * (blockIdx.y + 1) / gridDim.y);
 
     for (int m = tid; m < M; m += CLL_THREADS) sv[m] = vis[(size_t)b * M + m];
     __syncthreads();
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     if (a.w.w_camp > 0.f) fold(chi_ca, a.w.normalize, e_ca, d_ca);
     if (a.w.w_vis > 0.f) fold(chi_vis, a.w.normalize, e_vis, d_vis);
     if (a.w.w_amp > 0.f) fold(chi_amp, a.w.normalize, e_amp, d_amp);
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.y == 0) {
         // same accumulation order as loss(): vis, amp, cp, camp, flux (blackhole.py:742-769)
         float L = 0.f;
         if (a.w.w_vis > 0.f) L += a.w.w_vis * e_vis;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     const float f_vis = a.w.w_vis * d_vis / M;          // d/dv of |v-y|^2/(2 s^2 M) = (v-y)/(s^2 M)
     const float f_amp = a.w.w_amp * d_amp * 2.0f / M;
     __syncthreads();                                     // dcp / dca complete
-    for (int m = tid; m < M; m += CLL_THREADS) {
+    for (int m = m0 + tid; m < m1; m += CLL_THREADS) {
         const float2 v = sv[m];
         const float n2 = v.x * v.x + v.y * v.y;
         float gp = 0.f, gl = 0.f;                        // coefficients of i v/|v|^2 and v/|v|^2
@@ -233,12 +240,13 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
         }
         gvis[(size_t)b * M + m] = make_float2(gx, gy);
     }
-    for (int t = tid; t < T; t += CLL_THREADS) {
-        float g = 0.f;
-        if (a.w.w_flux > 0.f)
-            g = a.w.w_flux * (flux[(size_t)b * T + t] - (a.y.flux + yb * T)[t]) * 0.5f / T;
-        gflux[(size_t)b * T + t] = g;
-    }
+    if (blockIdx.y == 0)
+        for (int t = tid; t < T; t += CLL_THREADS) {
+            float g = 0.f;
+            if (a.w.w_flux > 0.f)
+                g = a.w.w_flux * (flux[(size_t)b * T + t] - (a.y.flux + yb * T)[t]) * 0.5f / T;
+            gflux[(size_t)b * T + t] = g;
+        }
 }
 
 static int check_tables(const char* who, const bh_tables_t* tab) {
@@ -272,13 +280,20 @@ extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
     const size_t base = (2 * (size_t)tab->n_vis + tab->n_tri + tab->n_quad + 96) * sizeof(float);
     const size_t staged = base + (2 * ((size_t)tab->n_vis + 1) + 3 * (size_t)tab->n_tri +
                                   4 * (size_t)tab->n_quad) * sizeof(int);
+    // the kernel is latency-bound and B workgroups leave most CUs idle: split the backward gather
+    // of a chain over several workgroups while the grid stays within one round
+    int parts = 1;
+#ifndef CLL_PARTS
+#define CLL_PARTS 4
+#endif
+    if (gvis_c64) while (parts < CLL_PARTS && B * parts * 2 <= 256) parts *= 2;
     if (staged <= 150 * 1024) {
         step_allow_lds((const void*)k_closure_loss<true>, staged);
-        hipLaunchKernelGGL(k_closure_loss<true>, dim3(B), dim3(CLL_THREADS), staged, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_closure_loss<true>, dim3(B, parts), dim3(CLL_THREADS), staged, (hipStream_t)stream,
                            (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
     } else {
         step_allow_lds((const void*)k_closure_loss<false>, base);
-        hipLaunchKernelGGL(k_closure_loss<false>, dim3(B), dim3(CLL_THREADS), base, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_closure_loss<false>, dim3(B, parts), dim3(CLL_THREADS), base, (hipStream_t)stream,
                            (const float2*)vis_c64, flux, a, loss, chi2, (float2*)gvis_c64, gflux);
     }
     STEP_CHECK_LAUNCH("bh_closure_loss");
