@@ -5,7 +5,8 @@
 // Same arithmetic as k_mri_loss_grad (mri_fft.hip) -- 192 = 16 x 12 in-register passes over LDS,
 // pruned to the kept k_y rows, fftshift folded into signs -- but scheduled differently:
 //   * software-pipelined column passes: while a thread transforms pass A of strip s (inputs
-//     loaded from global memory straight into the pass-A register layout, two strips ahead) it
+//     loaded from global memory straight into the pass-A register layout, up to three strips
+//     ahead, in register sets that rotate by name) it
 //     also finishes pass B of strip s-1 from registers; the strip buffer only carries the
 //     A -> B exchange: two barriers and 28 LDS accesses per thread and strip instead of three
 //     barriers and 83;
@@ -261,13 +262,18 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
 
     const int frame = ctx.block();
     if (frame >= nframes) return;
-    cf32 an[16], an2[16];                            // pass-A inputs, one and two strips ahead
+    // Pass-A inputs in flight: register sets that ROTATE by name (the strip loop is unrolled over
+    // them) -- copying a set into the next would wait for loads that are not needed yet.  Set k
+    // holds strip s = k mod NSETS; it is refilled with strip s + NSETS as soon as its pass-A
+    // results are in the strip buffer.  Three sets, or two when the measurement prefetch (YQ)
+    // needs the registers.
+    cf32 a0[16], a1[16], a2[16];
     {
         LG2_IDS(t0)
+        const float* xf = x + (size_t)frame * fsz;
         if (a_task) {
-            lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA, an);
-            if (!YQ)     // registers allow the second strip only without the measurement prefetch
-                lg2_load_strip(x + (size_t)frame * fsz, x + (size_t)frame * fsz + R * R, offA + SW * 4u, an2);
+            lg2_load_strip(xf, xf + R * R, offA, a0);
+            lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
         }
     }
 
@@ -325,73 +331,75 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         {
         LG2_IDS(t2)
         const float sgB = lg2_sgn(g);                // (-1)^ky for ky = g + 16 d
-        cf32 a[16], u[12];
+        cf32 u[12];
+        constexpr int NSETS = YQ ? 2 : 3;
+        if (!YQ && a_task) lg2_load_strip(xr, xi, offA + 2 * SW * 4u, a2);
         float4 yq[LG2_YQ];
         if (YQ) {
 #pragma unroll
             for (int i = 0; i < LG2_YQ; ++i) yq[i].x = yq[i].y = yq[i].z = yq[i].w = 0.f;
         }
-#pragma unroll 1
-        for (int s = 0; s < NS; ++s) {
-            if (a_task) {
-                if (!YQ) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { a[i] = an[i]; an[i] = an2[i]; }
-                    unsigned o = offA + (unsigned)(s + 2) * (SW * 4u);
-                    LG2_OPAQUE(o);
-                    if (s + 2 < NS) lg2_load_strip(xr, xi, o, an2);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) a[i] = an[i];
-                    unsigned o = offA + (unsigned)(s + 1) * (SW * 4u);
-                    LG2_OPAQUE(o);
-                    if (s + 1 < NS) lg2_load_strip(xr, xi, o, an);
-                }
-            }
-            if (YQ) {
-                // masked-out rows 32 s .. 32 s + 31 of the measurement (both planes), fetched a
-                // strip ahead of their use; kept rows stay zero here (the row phase has them)
-#pragma unroll
-                for (int i = 0; i < LG2_YQ; ++i) {
-                    acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
-                    const int e = tid + i * LG2_THREADS;             // < 32 rows * 2 planes * Q
-                    const int row = 32 * s + e / (2 * Q), r = e % (2 * Q), pl = r >= Q;
-                    yq[i].x = yq[i].y = yq[i].z = yq[i].w = 0.f;
-                    if (L.rowpos[row] < 0)
-                        yq[i] = *(const float4*)((const char*)yr +
-                                                 (unsigned)(pl * R * R + row * R + 4 * (r - pl * Q)) * 4u);
-                }
-            }
-            LG2_FENCE();
-            if (s > 0) {                             // pass B of strip s-1, kept rows -> Rk
-                fft192_pass_b<-1>(u);
-                const int n = lg2_phys((s - 1) * SW + col);
-                unsigned rq[3] = {rpB[0], rpB[1], rpB[2]};
-                LG2_OPAQUE(rq[0]); LG2_OPAQUE(rq[1]); LG2_OPAQUE(rq[2]);
-#pragma unroll
-                for (int d = 0; d < 12; ++d) {
-                    const int j = LG2_RP(rq, d);
-                    if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y);
-                }
-            }
-            LG2_FENCE();
-            if (a_task) {                            // pass A of strip s
-                fft16<-1>(a);
-#pragma unroll
-                for (int c = 1; c < 16; ++c) {
-                    const cf32 w = L.tw[bb * c];
-                    a[c] = c_rot<-1>(a[c], w.x, w.y);
-                }
-            }
-            ctx.sync();
-            if (a_task) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = a[c];
-            }
-            ctx.sync();
-#pragma unroll
-            for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col];
+        // one stage: pass B of strip s - 1 (from u), pass A of strip s (register set `cur`), the
+        // A -> B exchange through the strip buffer, then `cur` is refilled with strip s + NSETS
+#define LG2_FWD_STAGE(s, cur)                                                          \
+        {                                                                              \
+            if (YQ) {                                                                  \
+                /* masked-out rows 32 s .. 32 s + 31 of the measurement (both planes), fetched a */ \
+                /* strip ahead of their use; kept rows stay zero here (the row phase has them) */  \
+                _Pragma("unroll") for (int i = 0; i < LG2_YQ; ++i) {                   \
+                    acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w; \
+                    const int e = tid + i * LG2_THREADS;     /* < 32 rows * 2 planes * Q */ \
+                    const int row = 32 * (s) + e / (2 * Q), r = e % (2 * Q), pl = r >= Q; \
+                    yq[i].x = yq[i].y = yq[i].z = yq[i].w = 0.f;                       \
+                    if (L.rowpos[row] < 0)                                             \
+                        yq[i] = *(const float4*)((const char*)yr +                     \
+                                                 (unsigned)(pl * R * R + row * R + 4 * (r - pl * Q)) * 4u); \
+                }                                                                      \
+            }                                                                          \
+            LG2_FENCE();                                                               \
+            if ((s) > 0) {                   /* pass B of strip s-1, kept rows -> Rk */ \
+                fft192_pass_b<-1>(u);                                                  \
+                const int n = lg2_phys(((s) - 1) * SW + col);                          \
+                unsigned rq[3] = {rpB[0], rpB[1], rpB[2]};                             \
+                LG2_OPAQUE(rq[0]); LG2_OPAQUE(rq[1]); LG2_OPAQUE(rq[2]);               \
+                _Pragma("unroll") for (int d = 0; d < 12; ++d) {                       \
+                    const int j = LG2_RP(rq, d);                                       \
+                    if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y); \
+                }                                                                      \
+            }                                                                          \
+            LG2_FENCE();                                                               \
+            if (a_task) {                    /* pass A of strip s */                   \
+                fft16<-1>(cur);                                                        \
+                _Pragma("unroll") for (int c = 1; c < 16; ++c) {                       \
+                    const cf32 w = L.tw[bb * c];                                       \
+                    cur[c] = c_rot<-1>(cur[c], w.x, w.y);                              \
+                }                                                                      \
+            }                                                                          \
+            ctx.sync();                                                                \
+            if (a_task) {                                                              \
+                _Pragma("unroll") for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = cur[c]; \
+                unsigned o = offA + (unsigned)((s) + NSETS) * (SW * 4u);               \
+                LG2_OPAQUE(o);                                                         \
+                if ((s) + NSETS < NS) lg2_load_strip(xr, xi, o, cur);                  \
+            }                                                                          \
+            ctx.sync();                                                                \
+            _Pragma("unroll") for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col]; \
         }
+        if (YQ) {
+#pragma unroll 1
+            for (int s = 0; s < NS; s += 2) {
+                LG2_FWD_STAGE(s, a0)
+                LG2_FWD_STAGE(s + 1, a1)
+            }
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < NS; s += 3) {
+                LG2_FWD_STAGE(s, a0)
+                LG2_FWD_STAGE(s + 1, a1)
+                LG2_FWD_STAGE(s + 2, a2)
+            }
+        }
+#undef LG2_FWD_STAGE
         ctx.tick(1, frame);
         if (YQ) {
 #pragma unroll
