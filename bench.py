@@ -126,7 +126,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
