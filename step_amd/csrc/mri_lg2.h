@@ -271,10 +271,9 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
     {
         LG2_IDS(t0)
         const float* xf = x + (size_t)frame * fsz;
-        if (a_task) {
-            lg2_load_strip(xf, xf + R * R, offA, a0);
-            lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
-        }
+        // only the first strip before the set-up: a wave may have 63 loads outstanding and the
+        // 64th would hold it at the issue until a load returns, with the tables still to build
+        if (a_task) lg2_load_strip(xf, xf + R * R, offA, a0);
     }
 
     // per-thread constants of a mask frame: the row-buffer
@@ -291,6 +290,10 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             nk = nrows[mf];
             lg2_tables(ctx, L, rows + (size_t)mf * R, nk);
             LG2_IDS(t1)
+            if (a_task) {
+                const float* xf = x + (size_t)frame * fsz;
+                lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 rpA[i] = 0;
