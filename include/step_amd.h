@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);
+int         step_abi_version(void);   /* 2 since mri_loss_grad takes a 2*B*T workspace */
 
 /* ------------------------------------------------------------------ host-side tables */
 

@@ -22,7 +22,7 @@ void step_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* step_last_error(void) { return g_err; }
-extern "C" int step_abi_version(void) { return 1; }
+extern "C" int step_abi_version(void) { return 2; }   // 2: mri_loss_grad workspace is 2*B*T floats
 
 #define REQ(cond, ...)                      \
     do {                                    \
