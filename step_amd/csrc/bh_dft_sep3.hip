@@ -142,6 +142,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     const int li = lane & 31, h = lane >> 5;
     const int n_it = min(cpw, B - b0);
 
+#pragma unroll
     for (int u = tid; u < (H / 16) * 64; u += S3_THREADS) {
         const int col = u & 63, yg = u >> 6;                 // col = part*32 + f, yg = 2 kb + h
         const float* src = ey_t + ((size_t)t * H + yg * 8) * 64 + col;
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const int li = lane & 31, h = lane >> 5;
     const int n_it = min(cpw, B - b0);
 
+#pragma unroll
     for (int u = tid; u < 8 * HH; u += S3_THREADS) {
         const int y = u % HH, q = u / HH;                    // q = (part*2 + kb)*2 + h
         const int hh = q & 1, kb = (q >> 1) & 1, part = q >> 2;
