@@ -37,7 +37,7 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, x, op, y):
         need = ctx.needs_input_grad[0]
         loss, grad = op._launch_loss_grad(_f32c(x, x.device), y, need, None)
-        ctx.dtype = x.dtype
+        ctx.dtype, ctx.op = x.dtype, op
         if need:
             ctx.save_for_backward(grad)
         return loss
@@ -46,6 +46,8 @@ class _LossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
         (grad,) = ctx.saved_tensors
+        if ctx.op._unit_upstream:          # LatentWrapper.gradient: the loss is only summed
+            return grad.to(ctx.dtype), None, None
         g = grad * grad_loss.to(grad.dtype).view(-1, 1, 1, 1, 1)
         return g.to(ctx.dtype), None, None
 
@@ -77,6 +79,7 @@ class DynamicMRI(Operator):
         self._dev_tables = {}
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
+    _unit_upstream = False   # set by LatentWrapper.gradient around its autograd.grad call
 
     def _tables(self, device):
         key = str(device)
