@@ -208,11 +208,11 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
  * grad = chain_scale[b] * d loss[b] / d x  (autograd of the above; Appendix B "MRI").
  * grad may be NULL (loss only).  chain_scale may be NULL (=1).
  * loss_part: workspace float[2*B*T] (per-frame partial losses, then shares of the masked-out
- * rows' sum |y|^2 of a batch-1 measurement); loss [B]. */
+ * rows' sum |y|^2 of a batch-1 measurement); loss [B]; loss_total (may be NULL): sum of loss[]. */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
-                  const float* chain_scale, float* loss_part, float* loss, float* grad,
-                  void* stream);
+                  const float* chain_scale, float* loss_part, float* loss, float* loss_total,
+                  float* grad, void* stream);
 
 /* ------------------------------------------------------------------ MCMC state update */
 

@@ -469,10 +469,12 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
 
 // loss[b] = sum_t part[b][t] + sum of unk[0 .. n_unk): the shares of the masked-out rows' |y|^2
 // of a batch-1 measurement, which the pipelined kernel sums once for all chains (n_unk = 0
-// when the partial losses already hold them)
+// when the partial losses already hold them); total (optional) = sum_b loss[b], the scalar that
+// gradient(return_loss=True) returns (sampler/daps.py:100) -- one launch less per step
 __global__ __launch_bounds__(256) void k_mri_loss_finish(const float* __restrict__ part,
                                                          const float* __restrict__ unk, int n_unk,
-                                                         int B, int T, float* __restrict__ loss) {
+                                                         int B, int T, float* __restrict__ loss,
+                                                         float* __restrict__ total) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     float v = 0.f;
@@ -484,12 +486,24 @@ __global__ __launch_bounds__(256) void k_mri_loss_finish(const float* __restrict
         __syncthreads();
     }
     const float su = red[0];
-    for (int b = blockIdx.x * 256 + tid; b < B; b += gridDim.x * 256) {
+    float mine = 0.f;                                        // one block: b = tid, tid + 256, ...
+    for (int b = tid; b < B; b += 256) {
         const float* p = part + (size_t)b * T;
         float s = 0.f;
 #pragma unroll 4
         for (int t = 0; t < T; ++t) s += p[t];
         loss[b] = s + su;
+        mine += s + su;
+    }
+    if (total) {                                             // sum over the chains, fixed order
+        __syncthreads();
+        red[tid] = mine;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) *total = red[0];
     }
 }
 
@@ -540,7 +554,7 @@ extern "C" int mri_adjoint(const float* g, int B, int T, int R, const int32_t* r
 extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                              const int32_t* rows, const int32_t* nrows, int mask_frames,
                              int max_rows, const float* chain_scale, float* loss_part, float* loss,
-                             float* grad, void* stream) {
+                             float* loss_total, float* grad, void* stream) {
     STEP_REQUIRE(x && y && loss_part && loss, "mri_loss_grad: null pointer");
     STEP_REQUIRE(y_batch == 1 || y_batch == B, "mri_loss_grad: measurement batch %d vs B=%d", y_batch, B);
     if (int rc = mri_check("mri_loss_grad", B, T, R, rows, nrows, mask_frames)) return rc;
@@ -571,7 +585,7 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
                            rows, nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
     }
     STEP_CHECK_LAUNCH("mri_loss_grad");
-    hipLaunchKernelGGL(k_mri_loss_finish, dim3((B + 255) / 256), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss);
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss, loss_total);
     STEP_CHECK_LAUNCH("mri_loss_finish");
     return STEP_OK;
 }

@@ -126,7 +126,7 @@ class DynamicMRI(Operator):
                              % (tuple(y.shape), tuple(x.shape)))
         rows, nrows = self._tables(x.device)
         part = torch.empty(2 * B * T, device=x.device, dtype=torch.float32)
-        loss = torch.empty(B, device=x.device, dtype=torch.float32)
+        loss = torch.empty(B + 1, device=x.device, dtype=torch.float32)   # [B] per chain + their sum
         grad = torch.empty_like(x) if need_grad else None
         t0 = None
         if self._prof is not None:
@@ -135,14 +135,15 @@ class DynamicMRI(Operator):
         rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
                                       self.resolution, rows.data_ptr(), nrows.data_ptr(),
                                       self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
-                                      part.data_ptr(), loss.data_ptr(), _lib.ptr(grad),
-                                      _lib.stream_of(x))
+                                      part.data_ptr(), loss.data_ptr(),
+                                      loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
         if t0 is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(torch.cuda.current_stream(x.device))
             self._prof.setdefault("mri_loss_grad", []).append((t0, t1))
         _lib.check(rc, "mri_loss_grad")
-        return loss, grad
+        self._loss_total = loss[B]           # scalar sum over the chains, summed by the finish kernel
+        return loss[:B], grad
 
     # ------------------------------------------------------------------ reference API
     def __call__(self, x):
@@ -156,5 +157,5 @@ class DynamicMRI(Operator):
         loss, grad = self._launch_loss_grad(_f32c(x, x.device), y, True, None)
         grad = grad.to(x.dtype)
         if return_loss:
-            return grad, loss.sum()
+            return grad, self._loss_total
         return grad
