@@ -42,6 +42,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef S3_RING
 #define S3_RING 4
 #endif
+#define S3_GCH 64          // adjoint: chains whose g is staged in LDS at a time
+#define S3_GROW 68         // floats per staged chain: 32 x (re, im), flux, pad to 16 bytes
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -96,7 +98,11 @@ static int s3_cu_count() {
     return n;
 }
 
-// chains per workgroup: one resident workgroup per CU, every CU busy, no second round
+// chains per workgroup: one resident workgroup per CU, every CU busy, no second round.
+// The grid is 1-D with t = id % T, chain group = id / T: workgroup ids go round the 8 XCDs, so XCD c
+// streams the frames with t % 8 == c.  Which XCD touches which frames matters to the memory
+// system: the same stores from a (gx, T) grid -- XCD c gets one chain group and the t of one
+// parity -- take 8 % longer (scripts/probes/store_probe.*: 0.209 -> 0.194 ms per GB).
 static void s3_grid(int B, int T, int* cpw, int* gx) {
     int per_t = s3_cu_count() / T;
     per_t = per_t < 1 ? 1 : (per_t > B ? B : per_t);
@@ -137,10 +143,22 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     static_assert(NKB % R == 0, "ring must divide the block count");
     u32x4* eyp = lds4;
     float* sred = (float*)(lds4 + NKB * 384);
-    const int t = blockIdx.y, b0 = blockIdx.x * cpw;
+    const int t = blockIdx.x % T, b0 = (blockIdx.x / T) * cpw;   // s3_grid: why a 1-D grid
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n_it = min(cpw, B - b0);
+    const bool mine = strip < NSTRIP;                        // W < 256: the spare waves idle
+    const int xcol = (mine ? strip : 0) * 32 + li;
+    // ex of this lane's accumulator rows, held in registers for all chains: loads in the
+    // per-chain epilogue would wait behind the x blocks already in flight for the next chain
+    // (vmcnt counts in order) and drain the ring at every chain boundary
+    float exv_r[16], exv_i[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = mfma32_row(r, h);
+        exv_r[r] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
+        exv_i[r] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
+    }
 
 #pragma unroll
     for (int u = tid; u < (H / 16) * 64; u += S3_THREADS) {
@@ -157,11 +175,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     }
     __syncthreads();
 
-    const bool mine = strip < NSTRIP;                        // W < 256: the spare waves idle
-    const int xcol = (mine ? strip : 0) * 32 + li;
     const u32x4* ap = eyp + h * 32 + li;
-    const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W + xcol;
-    const float* exi = ex_ri + ((size_t)t * 2 + 1) * 32 * W + xcol;
     const size_t frame = (size_t)H * W;
     // pointer to row 8h of the chain's frame; the mirror rows are addressed from it too
     auto frame_ptr = [&](int it) { return x + ((size_t)(b0 + it) * T + t) * frame + 8 * h * W + xcol; };
@@ -206,7 +220,12 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     const float* xcur = frame_ptr(0);
     if (mine) {
 #pragma unroll
-        for (int s = 0; s < R - 1; ++s) { S3_LOAD(xq[s], xcur, s); }
+        for (int s = 0; s < R - 1; ++s) {
+            // block after block, as in the loop: the wait counts of the loop's stages are the
+            // merge of both paths, and a shuffled issue order here makes every stage over-wait
+            S3_LOAD(xq[s], xcur, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = mfma32_row(r, h);
-                const float er = exr[f * W], ei = exi[f * W];
+                const float er = exv_r[r], ei = exv_i[r];
                 const float zr = mn0[r] + sm0[r], zi = mn1[r] + sm1[r];
                 const float pr = row16_sum(er * zr - ei * zi);
                 const float pi = row16_sum(er * zi + ei * zr);
@@ -271,11 +290,11 @@ static void launch_fwd_s3(const float* ey_t, const float* ex_ri, int T, int F, c
     const size_t lds = (size_t)(H / 32) * 384 * 16 + (size_t)2 * 2 * (W / 32) * 64 * 4;
     if (clip_min == -INFINITY) {
         step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, false>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false>), dim3(gx, T), dim3(S3_THREADS), lds, st,
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false>), dim3(gx * T), dim3(S3_THREADS), lds, st,
                            ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
     } else {
         step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, true>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, true>), dim3(gx, T), dim3(S3_THREADS), lds, st,
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, true>), dim3(gx * T), dim3(S3_THREADS), lds, st,
                            ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
     }
 }
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
     // optional rider: sum_out = sum(sum_in[0 .. sum_n)) in a fixed order (the scalar loss that
     // gradient(return_loss=True) returns, daps.py:100) -- saves a reduction launch per step
-    if (sum_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+    if (sum_out && blockIdx.x == 0 && threadIdx.x < 64) {
         float sacc = 0.f;
         for (int i = threadIdx.x; i < sum_n; i += 64) sacc += sum_in[i];
         sacc = wave_sum(sacc);
@@ -319,11 +338,23 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     }
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
     u32x4* eyp = lds4;
-    const int t = blockIdx.y, b0 = blockIdx.x * cpw;
+    float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
+    const int t = blockIdx.x % T, b0 = (blockIdx.x / T) * cpw;   // s3_grid: why a 1-D grid
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n_it = min(cpw, B - b0);
+    const bool mine = strip < NSTRIP;                        // W < 256: the spare waves only stage
+    const int xcol = (mine ? strip : 0) * 32 + li;
 
+    // this lane's baselines f = 16 kb + 8 h + j and their ex values (chain independent); issued
+    // ahead of the table staging so that the two cold fetches overlap
+    float exr[16], exi[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int f = (q >> 3) * 16 + 8 * h + (q & 7);
+        exr[q] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
+        exi[q] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
+    }
 #pragma unroll
     for (int u = tid; u < 8 * HH; u += S3_THREADS) {
         const int y = u % HH, q = u / HH;                    // q = (part*2 + kb)*2 + h
@@ -337,85 +368,88 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         u32x4* dst = eyp + (((part * 2 + kb) * 3) * 2 + hh) * HH + y;
         dst[0] = p0; dst[2 * HH] = p1; dst[4 * HH] = p2;
     }
-    __syncthreads();
-    if (strip >= NSTRIP) return;                             // W < 256: no barrier below
-
-    const int xcol = strip * 32 + li;
-    // this lane's baselines f = 16 kb + 8 h + j and their ex values (chain independent)
-    float exr[16], exi[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int f = (q >> 3) * 16 + 8 * h + (q & 7);
-        exr[q] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
-        exi[q] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
-    }
-    float gr[16], gi[16], gfl;
 #ifdef EXP3_NT_STORE
 #define S3_STG(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #else
 #define S3_STG(ptr, v) (*(ptr) = (v))
 #endif
-#define S3_GLOAD(b)                                                                          \
-    {                                                                                        \
-        const float2* gp_ = (const float2*)gvis + ((size_t)(b) * T + t) * F;                 \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                     \
-            const int f = (q >> 3) * 16 + 8 * h + (q & 7);                                   \
-            const float2 g_ = gp_[min(f, F - 1)];                                            \
-            gr[q] = g_.x; gi[q] = g_.y;                                                      \
-        }                                                                                    \
-        gfl = gflux[(size_t)(b) * T + t];                                                    \
-    }
-    S3_GLOAD(b0);
     const u32x4* ap = eyp + h * HH + li;
+    // g of up to S3_GCH chains goes through LDS: a global load of the next chain's g inside the
+    // chain loop would be waited for with vmcnt(0) -- loads and stores share that counter, in
+    // order -- and every chain would start by draining the previous chain's 128 stores per lane
 #pragma unroll 1
-    for (int it = 0; it < n_it; ++it) {
-        const int b = b0 + it;
-        const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
-        u32x4 rh[2], rm[2], rl[2], ih[2], im[2], il[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float wr[8], wi[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int q = kb * 8 + j, f = kb * 16 + 8 * h + j;
-                const float a = cs * gr[q], c = cs * gi[q];
-                float vr = exr[q] * a + exi[q] * c, vi = exr[q] * c - exi[q] * a;
-                if (f >= F) { vr = (f == F) ? cs * gfl : 0.f; vi = 0.f; }
-                wr[j] = vr; wi[j] = vi;
+    for (int c0 = 0; c0 < n_it; c0 += S3_GCH) {
+        const int nch = min(S3_GCH, n_it - c0);
+        __syncthreads();                                     // planes staged / gl free again
+        for (int u = tid; u < nch * 33; u += S3_THREADS) {
+            const int c = u / 33, e = u - c * 33;
+            const size_t bt = (size_t)(b0 + c0 + c) * T + t;
+            if (e < 32) {
+                const float2 g_ = ((const float2*)gvis)[bt * F + min(e, F - 1)];
+                *(float2*)(gl + c * S3_GROW + 2 * e) = g_;
+            } else {
+                gl[c * S3_GROW + 64] = gflux[bt];
             }
-            split3(wr, rh[kb], rm[kb], rl[kb]);
-            split3(wi, ih[kb], im[kb], il[kb]);
         }
-        S3_GLOAD(min(b + 1, B - 1));                         // next chain's g rides under the tiles
-        float* gf = grad + ((size_t)b * T + t) * H * W + xcol;
+        __syncthreads();
+        if (!mine) continue;
 #pragma unroll 1
-        for (int tile = 0; tile < NTILE; ++tile) {
-            f32x16 ev, od;
+        for (int ic = 0; ic < nch; ++ic) {
+            const int b = b0 + c0 + ic;
+            const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
+            const float* gc = gl + ic * S3_GROW;
+            const float gfl = gc[64];
+            u32x4 rh[2], rm[2], rl[2], ih[2], im[2], il[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ev[r] = od[r] = 0.f;
+            for (int kb = 0; kb < 2; ++kb) {
+                const float4* g4 = (const float4*)(gc + 2 * (kb * 16 + 8 * h));
+                float gr[8], gi[8];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                if (kb < nkb) {
-                    const u32x4* a = ap + kb * (6 * HH) + tile * 32;
-                    {
-                        const u32x4 ah = a[0], am = a[2 * HH], al = a[4 * HH];
-                        S3_SIX(ah, am, al, rh[kb], rm[kb], rl[kb], ev, ev)
-                    }
-                    {
-                        const u32x4 ah = a[12 * HH], am = a[14 * HH], al = a[16 * HH];
-                        S3_SIX(ah, am, al, ih[kb], im[kb], il[kb], od, od)
-                    }
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 g_ = g4[jj];
+                    gr[2 * jj] = g_.x; gi[2 * jj] = g_.y; gr[2 * jj + 1] = g_.z; gi[2 * jj + 1] = g_.w;
                 }
-            const int ytop = tile * 32 + 4 * h;
+                float wr[8], wi[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int y = ytop + (r & 3) + 8 * (r >> 2);
-                S3_STG(gf + y * W, ev[r] + od[r]);
-                S3_STG(gf + (H - 1 - y) * W, ev[r] - od[r]);
+                for (int j = 0; j < 8; ++j) {
+                    const int q = kb * 8 + j, f = kb * 16 + 8 * h + j;
+                    const float a = cs * gr[j], c = cs * gi[j];
+                    float vr = exr[q] * a + exi[q] * c, vi = exr[q] * c - exi[q] * a;
+                    if (f >= F) { vr = (f == F) ? cs * gfl : 0.f; vi = 0.f; }
+                    wr[j] = vr; wi[j] = vi;
+                }
+                split3(wr, rh[kb], rm[kb], rl[kb]);
+                split3(wi, ih[kb], im[kb], il[kb]);
+            }
+            float* gf = grad + ((size_t)b * T + t) * H * W + xcol;
+#pragma unroll 1
+            for (int tile = 0; tile < NTILE; ++tile) {
+                f32x16 ev, od;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ev[r] = od[r] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    if (kb < nkb) {
+                        const u32x4* a = ap + kb * (6 * HH) + tile * 32;
+                        {
+                            const u32x4 ah = a[0], am = a[2 * HH], al = a[4 * HH];
+                            S3_SIX(ah, am, al, rh[kb], rm[kb], rl[kb], ev, ev)
+                        }
+                        {
+                            const u32x4 ah = a[12 * HH], am = a[14 * HH], al = a[16 * HH];
+                            S3_SIX(ah, am, al, ih[kb], im[kb], il[kb], od, od)
+                        }
+                    }
+                const int ytop = tile * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int y = ytop + (r & 3) + 8 * (r >> 2);
+                    S3_STG(gf + y * W, ev[r] + od[r]);
+                    S3_STG(gf + (H - 1 - y) * W, ev[r] - od[r]);
+                }
             }
         }
     }
-#undef S3_GLOAD
 #undef S3_STG
 }
 
@@ -425,9 +459,9 @@ static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, 
                           float* grad, const float* sum_in, int sum_n, float* sum_out, hipStream_t st) {
     int cpw, gx;
     s3_grid(B, T, &cpw, &gx);
-    const size_t lds = (size_t)24 * (H / 2) * 16;
+    const size_t lds = (size_t)24 * (H / 2) * 16 + (size_t)S3_GCH * S3_GROW * 4;
     step_allow_lds((const void*)k_dft_adj_s3<H, W>, lds);
-    hipLaunchKernelGGL((k_dft_adj_s3<H, W>), dim3(gx, T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
+    hipLaunchKernelGGL((k_dft_adj_s3<H, W>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
                        gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out);
 }
 
