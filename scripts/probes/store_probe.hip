@@ -186,7 +186,35 @@ __global__ __launch_bounds__(512) void k_store15(float* out, int B, int cpw) {
             }
     }
 }
+// (m) XCD mapping of (l); ORDER 0: the frame written linearly, 2 KB (two rows) per round of the
+// workgroup; ORDER 1: tile by tile -- 32 rows from the top linearly, then their 32 mirror rows
+// linearly -- what the adjoint could store if its tiles went through LDS
+template <int ORDER>
+__global__ __launch_bounds__(512) void k_store18(float* out, int B, int cpw) {
+    const int t = blockIdx.x & 63, b0 = (blockIdx.x >> 6) * cpw;
+    const int tid = threadIdx.x;
+    for (int it = 0; it < cpw && b0 + it < B; ++it) {
+        float* f = out + ((size_t)(b0 + it) * 64 + t) * 65536;
+        if (ORDER == 0) {
+#pragma unroll 8
+            for (int q = 0; q < 128; ++q) f[q * 512 + tid] = 1.f;
+        } else {
+            for (int tile = 0; tile < 4; ++tile) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) f[(tile * 32 + 2 * q) * 256 + tid] = 1.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) f[(224 - tile * 32 + 2 * q) * 256 + tid] = 2.f;
+            }
+        }
+    }
+}
 extern "C" void store_probe(int mode, float* out, int B, void* stream) {
+    if (mode == 18 || mode == 19) {
+        const int cpw18 = (B + 3) / 4;
+        if (mode == 18) hipLaunchKernelGGL(k_store18<0>, dim3(((B + cpw18 - 1) / cpw18) * 64), dim3(512), 0, (hipStream_t)stream, out, B, cpw18);
+        else hipLaunchKernelGGL(k_store18<1>, dim3(((B + cpw18 - 1) / cpw18) * 64), dim3(512), 0, (hipStream_t)stream, out, B, cpw18);
+        return;
+    }
     if (mode == 15) {
         const int cpw15 = (B + 3) / 4;
         hipLaunchKernelGGL(k_store15<0>, dim3(((B + cpw15 - 1) / cpw15) * 64), dim3(512), 0, (hipStream_t)stream, out, B, cpw15);

@@ -42,6 +42,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef S3_RING
 #define S3_RING 4
 #endif
+// chain handled in iteration `it` by chain group g of gx: blocked (g * cpw + it) or, with
+// EXP3_RR, dealt round-robin (g + it * gx: all workgroups sweep the batch as one front)
+#ifdef EXP3_RR
+#define S3_CHAIN(it) (grp + (it) * ngrp)
+#define S3_NIT() ((B - grp + ngrp - 1) / ngrp)
+#else
+#define S3_CHAIN(it) (grp * cpw + (it))
+#define S3_NIT() min(cpw, B - grp * cpw)
+#endif
 #define S3_GCH 64          // adjoint: chains whose g is staged in LDS at a time
 #define S3_GROW 68         // floats per staged chain: 32 x (re, im), flux, pad to 16 bytes
 
@@ -143,10 +152,11 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     static_assert(NKB % R == 0, "ring must divide the block count");
     u32x4* eyp = lds4;
     float* sred = (float*)(lds4 + NKB * 384);
-    const int t = blockIdx.x % T, b0 = (blockIdx.x / T) * cpw;   // s3_grid: why a 1-D grid
+    const int t = blockIdx.x % T, grp = blockIdx.x / T, ngrp = gridDim.x / T;   // s3_grid: why a 1-D grid
+    (void)ngrp;
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int n_it = min(cpw, B - b0);
+    const int n_it = S3_NIT();
     const bool mine = strip < NSTRIP;                        // W < 256: the spare waves idle
     const int xcol = (mine ? strip : 0) * 32 + li;
     // ex of this lane's accumulator rows, held in registers for all chains: loads in the
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     const u32x4* ap = eyp + h * 32 + li;
     const size_t frame = (size_t)H * W;
     // pointer to row 8h of the chain's frame; the mirror rows are addressed from it too
-    auto frame_ptr = [&](int it) { return x + ((size_t)(b0 + it) * T + t) * frame + 8 * h * W + xcol; };
+    auto frame_ptr = [&](int it) { return x + ((size_t)S3_CHAIN(it) * T + t) * frame + 8 * h * W + xcol; };
 
     f32x16 mn0, mn1, sm0, sm1;
     float xq[R][16];
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
             float s = 0.f;
 #pragma unroll
             for (int p = 0; p < NPART; ++p) s += sp[p * 64];
-            const int b = b0 + it, c = lane >> 5, f = lane & 31;
+            const int b = S3_CHAIN(it), c = lane >> 5, f = lane & 31;
             if (f < F) vis[(((size_t)b * T + t) * F + f) * 2 + c] = s;
             else if (f == F && c == 0) flux[(size_t)b * T + t] = s;
         }
@@ -339,10 +349,11 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
     u32x4* eyp = lds4;
     float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
-    const int t = blockIdx.x % T, b0 = (blockIdx.x / T) * cpw;   // s3_grid: why a 1-D grid
+    const int t = blockIdx.x % T, grp = blockIdx.x / T, ngrp = gridDim.x / T;   // s3_grid: why a 1-D grid
+    (void)ngrp;
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int n_it = min(cpw, B - b0);
+    const int n_it = S3_NIT();
     const bool mine = strip < NSTRIP;                        // W < 256: the spare waves only stage
     const int xcol = (mine ? strip : 0) * 32 + li;
 
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         __syncthreads();                                     // planes staged / gl free again
         for (int u = tid; u < nch * 33; u += S3_THREADS) {
             const int c = u / 33, e = u - c * 33;
-            const size_t bt = (size_t)(b0 + c0 + c) * T + t;
+            const size_t bt = (size_t)S3_CHAIN(c0 + c) * T + t;
             if (e < 32) {
                 const float2 g_ = ((const float2*)gvis)[bt * F + min(e, F - 1)];
                 *(float2*)(gl + c * S3_GROW + 2 * e) = g_;
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         if (!mine) continue;
 #pragma unroll 1
         for (int ic = 0; ic < nch; ++ic) {
-            const int b = b0 + c0 + ic;
+            const int b = S3_CHAIN(c0 + ic);
             const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
             const float* gc = gl + ic * S3_GROW;
             const float gfl = gc[64];

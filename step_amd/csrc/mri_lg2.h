@@ -38,6 +38,11 @@
 #define LG2_YQ 6                  // float4 loads per thread and strip for the masked-out rows
 #define LG2_UNK_PARTS 16          // a batch-1 measurement: its masked-out rows are shared out
 
+#ifdef EXP_LG2_ALLTASK
+#define LG2_ALLTASK 1
+#else
+#define LG2_ALLTASK 0
+#endif
 #if defined(__HIPCC__)
 #define LG2_DEV __device__ __forceinline__
 // The value is declared modified: address arithmetic derived from it stays inside the loop
@@ -98,18 +103,20 @@ LG2_DEV void lg2_load_strip(const float* xr, const float* xi, unsigned off, cf32
 }
 
 // Tables of one mask frame.  The caller syncs before (LDS reuse) -- this function ends synced.
+// `my_row` = rowlist[tid] for tid < nk (nk <= LG2_NKC_MAX <= LG2_THREADS), fetched by the caller
+// ahead of the first strip: fetched here, behind the strip's 32 loads, the wait for it would be
+// a wait for the strip.
 template <class Ctx>
-LG2_DEV void lg2_tables(const Ctx& ctx, const Lg2Lds& L, const int* rowlist, int nk) {
+LG2_DEV void lg2_tables(const Ctx& ctx, const Lg2Lds& L, int my_row, int nk) {
     const int tid = ctx.tid();
     for (int e = tid; e < LG2_R; e += LG2_THREADS) {
         L.tw[e] = ctx.cos_sin_2pi_over_192(e);
         L.rowpos[e] = -1;
     }
     ctx.sync();
-    for (int e = tid; e < nk; e += LG2_THREADS) {
-        const int r = rowlist[e];
-        L.rowpos[r] = e;
-        L.rowl[e] = r;
+    if (tid < nk) {
+        L.rowpos[my_row] = tid;
+        L.rowl[tid] = my_row;
     }
     ctx.sync();
 }
@@ -254,8 +261,8 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
     int t_ = tid;                                                                      \
     LG2_OPAQUE(t_);                                                                    \
     const int col = t_ & 31, g = t_ >> 5;                                              \
-    const bool a_task = g < 12;                                                        \
-    const int bb = a_task ? g : 0;                                                     \
+    const bool a_task = LG2_ALLTASK || g < 12;                                         \
+    const int bb = g < 12 ? g : 0;                                                     \
     const unsigned offA = (unsigned)(bb * R + col) * 4u; /* (row bb, column col), strip 0 */ \
     const unsigned offB = (unsigned)(g * R + col) * 4u;  /* (row g, column col) */     \
     (void)offA; (void)offB;
@@ -268,12 +275,21 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
     // results are in the strip buffer.  Three sets, or two when the measurement prefetch (YQ)
     // needs the registers.
     cf32 a0[16], a1[16], a2[16];
+    int my_row;
     {
+        const int t_ = frame % T;
+        my_row = rows[(size_t)(mask_frames == 1 ? 0 : t_) * R + (tid < R ? tid : 0)];
         LG2_IDS(t0)
         const float* xf = x + (size_t)frame * fsz;
         // only the first strip before the set-up: a wave may have 63 loads outstanding and the
         // 64th would hold it at the issue until a load returns, with the tables still to build
-        if (a_task) lg2_load_strip(xf, xf + R * R, offA, a0);
+        // (the loads are not under `if (a_task)`: waves 6 and 7 fetch row 0 again and drop it.
+        // A load inside a divergent branch gives the compiler a path on which it was skipped;
+        // there an older set holds the youngest loads, and the wait counts, which must be right
+        // on every path, become "wait for everything" on all of them)
+        // YQ keeps the branch: its measurement prefetch is conditional anyway, and the extra
+        // loads only cost there.
+        if (!YQ || a_task) lg2_load_strip(xf, xf + R * R, offA, a0);
     }
 
     // per-thread constants of a mask frame: the row-buffer
@@ -288,9 +304,9 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         const int mf = mask_frames == 1 ? 0 : t;
         {
             nk = nrows[mf];
-            lg2_tables(ctx, L, rows + (size_t)mf * R, nk);
+            lg2_tables(ctx, L, my_row, nk);
             LG2_IDS(t1)
-            if (a_task) {
+            if (!YQ || a_task) {
                 const float* xf = x + (size_t)frame * fsz;
                 lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
             }
@@ -317,17 +333,6 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         float acc = 0.f, acc_u = 0.f;
         const int nparts = nframes / T < LG2_UNK_PARTS ? nframes / T : LG2_UNK_PARTS;
         const bool has_share = !YQ && b < nparts;        // uniform over the workgroup
-        if (has_share) {
-            const int r0 = b * R / nparts, r1 = (b + 1) * R / nparts;
-#pragma unroll 4
-            for (int e = tid; e < (r1 - r0) * 2 * Q; e += LG2_THREADS) {
-                const int row = r0 + e / (2 * Q), r = e % (2 * Q), pl = r >= Q;
-                if (L.rowpos[row] < 0) {
-                    const float4 v = *(const float4*)(yr + (size_t)pl * R * R + row * R + 4 * (r - pl * Q));
-                    acc_u += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                }
-            }
-        }
         ctx.tick(0, frame);
 
         // ---------------------------------------------------------------- forward column phase
@@ -336,7 +341,7 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
         const float sgB = lg2_sgn(g);                // (-1)^ky for ky = g + 16 d
         cf32 u[12];
         constexpr int NSETS = YQ ? 2 : 3;
-        if (!YQ && a_task) lg2_load_strip(xr, xi, offA + 2 * SW * 4u, a2);
+        if (!YQ) lg2_load_strip(xr, xi, offA + 2 * SW * 4u, a2);
         float4 yq[LG2_YQ];
         if (YQ) {
 #pragma unroll
@@ -381,13 +386,20 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             ctx.sync();                                                                \
             if (a_task) {                                                              \
                 _Pragma("unroll") for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = cur[c]; \
+            }                                                                          \
+            if ((s) + NSETS < NS && (!YQ || a_task)) {                                 \
                 unsigned o = offA + (unsigned)((s) + NSETS) * (SW * 4u);               \
                 LG2_OPAQUE(o);                                                         \
-                if ((s) + NSETS < NS) lg2_load_strip(xr, xi, o, cur);                  \
+                lg2_load_strip(xr, xi, o, cur);                                        \
             }                                                                          \
             ctx.sync();                                                                \
             _Pragma("unroll") for (int i = 0; i < 12; ++i) u[i] = L.S[(12 * g + i) * SW + col]; \
         }
+        // Straight-line, not a loop: the compiler derives each wait count from every path that
+        // reaches the instruction, and in a loop the last round -- nothing refilled, the set in
+        // use holds the youngest loads -- forces "wait for everything" on all rounds, which
+        // drains the sets that should stay in flight.
+        static_assert(NS == 6, "stages are written out");
         if (YQ) {
 #pragma unroll 1
             for (int s = 0; s < NS; s += 2) {
@@ -395,12 +407,8 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
                 LG2_FWD_STAGE(s + 1, a1)
             }
         } else {
-#pragma unroll 1
-            for (int s = 0; s < NS; s += 3) {
-                LG2_FWD_STAGE(s, a0)
-                LG2_FWD_STAGE(s + 1, a1)
-                LG2_FWD_STAGE(s + 2, a2)
-            }
+            LG2_FWD_STAGE(0, a0) LG2_FWD_STAGE(1, a1) LG2_FWD_STAGE(2, a2)
+            LG2_FWD_STAGE(3, a0) LG2_FWD_STAGE(4, a1) LG2_FWD_STAGE(5, a2)
         }
 #undef LG2_FWD_STAGE
         ctx.tick(1, frame);
@@ -418,6 +426,29 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
                 if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y);
             }
         }
+        }
+        // this chain's share of the masked-out measurement rows: here, where no strip is in
+        // flight (the wait for these loads is a wait for everything older), four loads at a
+        // time and none of them under a branch (a kept row is fetched and not added)
+        if (has_share) {
+            const int r0 = b * R / nparts, r1 = (b + 1) * R / nparts, ne = (r1 - r0) * 2 * Q;
+#pragma unroll 1
+            for (int e0 = tid; e0 < ne; e0 += 4 * LG2_THREADS) {
+                float4 v[4];
+                bool m[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = e0 + i * LG2_THREADS, ec = e < ne ? e : 0;
+                    const int row = r0 + ec / (2 * Q), r = ec % (2 * Q), pl = r >= Q;
+                    m[i] = e < ne && L.rowpos[row] < 0;
+                    v[i] = *(const float4*)(yr + (size_t)pl * R * R + row * R + 4 * (r - pl * Q));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float q = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+                    acc_u += m[i] ? q : 0.f;             // a select: a NaN in a kept row stays out
+                }
+            }
         }
         lg2_row_phase<LG2_THREADS>(ctx, L.Rk, L.tw, L.rowl, rows + (size_t)mf * R, nk, yr, yi, cs2,
                                    grad != nullptr, frame, acc);
