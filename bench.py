@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--steps", type=int, default=400)
     p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--task", default="blackhole", choices=["blackhole", "mri"])
-    p.add_argument("--batch", type=int, default=None, help="chains per GPU (default 64)")
+    p.add_argument("--batch", type=int, default=None, help="chains per GPU (default: blackhole 64, mri 256)")
     p.add_argument("--path", default="auto", choices=["auto", "sep3", "sep", "dense"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=8)
@@ -131,7 +131,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B = a.batch or 64
+    # blackhole B in {1, 8, 64} (config 4 runs 64 samples), MRI B in {1, 32, 256}
+    B = a.batch or (64 if a.task == "blackhole" else 256)
     gen = torch.Generator(device=dev).manual_seed(37 + rank)
 
     if a.task == "blackhole":
@@ -210,7 +211,7 @@ def main():
             gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                        traffic=measured_traffic("k_mri_loss_grad2", B == 64),
+                        traffic=measured_traffic("k_mri_loss_grad2", B == 256),
                         algorithmic="24*T*R*R bytes per chain x %d chains" % B, kernels_ms=kern)
         out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
                    unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
