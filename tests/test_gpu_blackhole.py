@@ -353,3 +353,60 @@ def test_from_tensors_finds_the_rank1_structure(dev):
     assert d.path == "dense"
     with pytest.raises(ValueError):
         BlackHoleImagingTorch.from_tensors(A + noise, *args[1:], dft="sep", **kw)
+
+
+@pytest.mark.parametrize("T,F,H,B", [(5, 6, 64, 7), (3, 28, 128, 2), (70, 10, 64, 9)])
+def test_sep3_other_frame_counts_through_the_abi(T, F, H, B, dev):
+    """The folded kernels deal frames to workgroups as t = id mod T on a 1-D grid: frame counts
+    that are not 64 (odd, not a multiple of 8, more than there are CUs / 4) and chain counts that
+    do not divide into the chain groups, called through the C ABI against an fp64 evaluation."""
+    from step_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(T * 100 + F)
+    half = rng.randn(T, F, H // 2) + 1j * rng.randn(T, F, H // 2)
+    ey = np.concatenate([half, np.conj(half[:, :, ::-1])], axis=2)          # ey[H-1-y] = conj(ey[y])
+    ex = rng.randn(T, F, H) + 1j * rng.randn(T, F, H)
+    ey_ri = np.zeros((T, 2, 32, H), np.float32)
+    ex_ri = np.zeros((T, 2, 32, H), np.float32)
+    ey_ri[:, 0, :F], ey_ri[:, 1, :F] = ey.real, ey.imag
+    ex_ri[:, 0, :F], ex_ri[:, 1, :F] = ex.real, ex.imag
+    ey_ri[:, 0, F], ex_ri[:, 0, F] = 1.0, 1.0                               # flux row
+    assert L.bh_sep3_tables_ok(_lib.ptr(ey_ri), T, H) == 1
+    ey_t = np.ascontiguousarray(ey_ri.reshape(T, 64, H).transpose(0, 2, 1))
+    d = lambda a: torch.from_numpy(a).to(dev)
+    ey_t_d, ey_ri_d, ex_ri_d = d(ey_t), d(ey_ri), d(ex_ri)
+    ey64 = ey_ri[:, 0, :F].astype(np.float64) + 1j * ey_ri[:, 1, :F].astype(np.float64)
+    ex64 = ex_ri[:, 0, :F].astype(np.float64) + 1j * ex_ri[:, 1, :F].astype(np.float64)
+
+    x = rng.rand(B, T, H, H).astype(np.float32) * 2 - 1
+    x_d = d(x)
+    vis = torch.empty(B, T * F, 2, device=dev)
+    flux = torch.empty(B, T, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.bh_dft_fwd_sep3(ey_t_d.data_ptr(), ex_ri_d.data_ptr(), T, F, H, H, x_d.data_ptr(), B,
+                           0.5, 0.5, float("-inf"), vis.data_ptr(), flux.data_ptr(), st)
+    _lib.check(rc, "bh_dft_fwd_sep3")
+    xp = x.astype(np.float64) * 0.5 + 0.5
+    want = np.einsum("tfy,btyx,tfx->btf", ey64, xp, ex64)
+    got = torch.view_as_complex(vis).cpu().numpy().reshape(B, T, F)
+    scale = np.einsum("tfy,btyx,tfx->btf", np.abs(ey64), np.abs(xp), np.abs(ex64)).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale
+    assert np.abs(flux.cpu().numpy() - xp.sum((2, 3))).max() <= 1e-5 * H * H
+
+    gv = (rng.randn(B, T, F) + 1j * rng.randn(B, T, F))
+    gfl = rng.randn(B, T)
+    cs = rng.rand(B).astype(np.float32) + 0.5
+    gv_d = d(np.stack([gv.real, gv.imag], -1).astype(np.float32).reshape(B, T * F, 2))
+    gfl_d, cs_d = d(gfl.astype(np.float32)), d(cs)
+    grad = torch.full((B, T, H, H), float("nan"), device=dev)
+    rc = L.bh_dft_adj_sep3(ey_ri_d.data_ptr(), ex_ri_d.data_ptr(), T, F, H, H, gv_d.data_ptr(),
+                           gfl_d.data_ptr(), cs_d.data_ptr(), B, 2.0, grad.data_ptr(), None, 0, None, st)
+    _lib.check(rc, "bh_dft_adj_sep3")
+    gv32 = gv_d.cpu().numpy().astype(np.float64).reshape(B, T, F, 2)
+    g64 = gv32[..., 0] + 1j * gv32[..., 1]
+    # grad[y][x] = Re sum_f conj(ey[f][y] ex[f][x]) g[f] + gflux
+    want = (np.einsum("tfy,tfx,btf->btyx", np.conj(ey64), np.conj(ex64), g64).real
+            + gfl_d.cpu().numpy().astype(np.float64)[:, :, None, None]) * (2.0 * cs.astype(np.float64))[:, None, None, None]
+    got = grad.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max() * np.sqrt(F)
