@@ -25,14 +25,16 @@
 //
 // Both kernels are persistent: a workgroup (8 waves, one 32-column strip each) owns frame t for
 // `cpw` chains, stages the frame's ey planes in LDS once (48 KB at H = 256) and walks its chains.
+// The grid is 1-D with t = id % T, so that XCD c streams the frames with t % 8 == c (s3_grid).
 // forward: a ring of R blocks (16 rows from the top + their 16 mirror rows, 16 dwords per lane
 //   per block) keeps R - 1 blocks in flight across chain boundaries; the leading products go to
 //   `mn`, the five corrections to `sm` (2^-8 of the leading term, their rounding never matters),
-//   so `mn` sees H/32 additions per output.  Epilogue: complex multiply by ex in the
-//   accumulator layout, DPP row sums, fixed-order sum over strips.
-// adjoint: per chain each wave folds g into its ex columns (w), splits w into planes in
-//   registers, and produces two mirrored 32x32 output tiles from 24 MFMAs; no barrier in the
-//   chain loop.
+//   so `mn` sees H/32 additions per output.  Epilogue: complex multiply by ex (held in
+//   registers: nothing is loaded in the chain loop but the ring) in the accumulator layout,
+//   DPP row sums, fixed-order sum over strips.
+// adjoint: g of up to 64 chains is staged in LDS; per chain each wave folds g into its ex columns
+//   (w), splits w into planes in registers, and produces two mirrored 32x32 output tiles from
+//   24 MFMAs; no barrier and no vector load in the chain loop.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
