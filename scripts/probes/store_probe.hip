@@ -208,7 +208,35 @@ __global__ __launch_bounds__(512) void k_store18(float* out, int B, int cpw) {
         }
     }
 }
+// (n) XCD mapping of (l), the adjoint's pattern, with DELAY x 64 cycles of s_sleep between tiles:
+// stands in for the matrix phase of a tile, during which the wave issues no store
+template <int DELAY>
+__global__ __launch_bounds__(512) void k_store20(float* out, int B, int cpw) {
+    const int t = blockIdx.x & 63, b0 = (blockIdx.x >> 6) * cpw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    for (int it = 0; it < cpw && b0 + it < B; ++it) {
+        float* f = out + ((size_t)(b0 + it) * 64 + t) * 65536;
+        for (int tile = 0; tile < 4; ++tile) {
+            if (DELAY) __builtin_amdgcn_s_sleep(DELAY);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int y = tile * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                f[y * 256 + wave * 32 + li] = (float)r;
+                f[(255 - y) * 256 + wave * 32 + li] = (float)tile;
+            }
+        }
+    }
+}
 extern "C" void store_probe(int mode, float* out, int B, void* stream) {
+    if (mode >= 20 && mode <= 23) {
+        const int cpw20 = (B + 3) / 4;
+        dim3 g20(((B + cpw20 - 1) / cpw20) * 64);
+        if (mode == 20) hipLaunchKernelGGL(k_store20<0>, g20, dim3(512), 0, (hipStream_t)stream, out, B, cpw20);
+        else if (mode == 21) hipLaunchKernelGGL(k_store20<12>, g20, dim3(512), 0, (hipStream_t)stream, out, B, cpw20);
+        else if (mode == 22) hipLaunchKernelGGL(k_store20<24>, g20, dim3(512), 0, (hipStream_t)stream, out, B, cpw20);
+        else hipLaunchKernelGGL(k_store20<48>, g20, dim3(512), 0, (hipStream_t)stream, out, B, cpw20);
+        return;
+    }
     if (mode == 18 || mode == 19) {
         const int cpw18 = (B + 3) / 4;
         if (mode == 18) hipLaunchKernelGGL(k_store18<0>, dim3(((B + cpw18 - 1) / cpw18) * 64), dim3(512), 0, (hipStream_t)stream, out, B, cpw18);
