@@ -61,6 +61,28 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
     const int* ca_ptr = a.tab.ca_ptr;
     const int* cp_ent = a.tab.cp_ent;
     const int* ca_ent = a.tab.ca_ent;
+    // The kernel is a chain of latencies, so every global load that depends on nothing is issued
+    // here, together: this chain's visibilities (the first two per thread; the rest, if any,
+    // below), and the table entries and measurement of the thread's first triangle and first
+    // quadrangle.  Issued one phase at a time they cost an L2 / HBM round trip each.
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
+    const float2 v_pre0 = vis[(size_t)b * M + min(tid, M - 1)];
+    const float2 v_pre1 = vis[(size_t)b * M + min(tid + CLL_THREADS, M - 1)];
+    int t_idx[3] = {0, 0, 0}, t_cj[3] = {0, 0, 0}, q_idx[4] = {0, 0, 0, 0};
+    float t_y = 0.f, t_s = 1.f, q_y = 0.f, q_s = 1.f;
+    if (a.w.w_cp > 0.f && tid < Kcp) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { t_idx[j] = a.tab.cp_index[3 * tid + j]; t_cj[j] = a.tab.cp_conj[3 * tid + j]; }
+        t_y = (a.y.cphase + yb * Kcp)[tid];
+        t_s = (a.y.sigma_cphase + yb * Kcp)[tid];
+    }
+    if (a.w.w_camp > 0.f && tid < Kca) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q_idx[j] = a.tab.camp_index[4 * tid + j];
+        q_y = (a.y.logcamp + yb * Kca)[tid];
+        q_s = (a.y.sigma_logcamp + yb * Kca)[tid];
+    }
     if (STAGED && gvis) {
         // only this workgroup's slice of the baselines: pointers [s0, s1] and the entries between
         // ptr[s0] and ptr[s1], kept at their global positions (the unused part of the LDS image
@@ -80,13 +102,13 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
         }
         cp_ptr = l_cp_ptr; ca_ptr = l_ca_ptr; cp_ent = l_cp_ent; ca_ent = l_ca_ent;
     }
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const size_t yb = a.y.batch > 1 ? (size_t)b : 0;
     // gridDim.y workgroups share a chain: every one of them evaluates the chi^2 sums (they need
     // all closure quantities), each takes a slice [m0, m1) of the baselines in the backward gather
     const int m0 = (int)((long long)M * blockIdx.y / gridDim.y), m1 = (int)((long long)M * (blockIdx.y + 1) / gridDim.y);
 
-    for (int m = tid; m < M; m += CLL_THREADS) sv[m] = vis[(size_t)b * M + m];
+    if (tid < M) sv[tid] = v_pre0;
+    if (tid + CLL_THREADS < M) sv[tid + CLL_THREADS] = v_pre1;
+    for (int m = tid + 2 * CLL_THREADS; m < M; m += CLL_THREADS) sv[m] = vis[(size_t)b * M + m];
     __syncthreads();
 
     // --- closure phase: chi = 2 mean((1 - cos(y - phi)) / s^2), blackhole.py:472-474
@@ -95,13 +117,18 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
         const float* yv = a.y.cphase + yb * Kcp;
         const float* ys = a.y.sigma_cphase + yb * Kcp;
         for (int k = tid; k < Kcp; k += CLL_THREADS) {
-            const float2 i1 = cdir(sv[a.tab.cp_index[3 * k + 0]], a.tab.cp_conj[3 * k + 0]);
-            const float2 i2 = cdir(sv[a.tab.cp_index[3 * k + 1]], a.tab.cp_conj[3 * k + 1]);
-            const float2 i3 = cdir(sv[a.tab.cp_index[3 * k + 2]], a.tab.cp_conj[3 * k + 2]);
+            if (k != tid) {                                // the first one came with the prologue
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { t_idx[j] = a.tab.cp_index[3 * k + j]; t_cj[j] = a.tab.cp_conj[3 * k + j]; }
+                t_y = yv[k]; t_s = ys[k];
+            }
+            const float2 i1 = cdir(sv[t_idx[0]], t_cj[0]);
+            const float2 i2 = cdir(sv[t_idx[1]], t_cj[1]);
+            const float2 i3 = cdir(sv[t_idx[2]], t_cj[2]);
             const float2 p = cmul(cmul(i1, i2), i3);
             const float phi = atan2f(p.y, p.x);
-            const float d = yv[k] - phi;
-            const float is2 = 1.0f / (ys[k] * ys[k]);
+            const float d = t_y - phi;
+            const float is2 = 1.0f / (t_s * t_s);
             s_cp += one_minus_cos(d) * is2;
             dcp[k] = -sinf(d) * is2;                       // d/dphi of (1 - cos(y - phi))/s^2
         }
@@ -112,14 +139,19 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
         const float* yv = a.y.logcamp + yb * Kca;
         const float* ys = a.y.sigma_logcamp + yb * Kca;
         for (int k = tid; k < Kca; k += CLL_THREADS) {
-            const float a1 = cabs(sv[a.tab.camp_index[4 * k + 0]]);
-            const float a2 = cabs(sv[a.tab.camp_index[4 * k + 1]]);
-            const float a3 = cabs(sv[a.tab.camp_index[4 * k + 2]]);
-            const float a4 = cabs(sv[a.tab.camp_index[4 * k + 3]]);
+            if (k != tid) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q_idx[j] = a.tab.camp_index[4 * k + j];
+                q_y = yv[k]; q_s = ys[k];
+            }
+            const float a1 = cabs(sv[q_idx[0]]);
+            const float a2 = cabs(sv[q_idx[1]]);
+            const float a3 = cabs(sv[q_idx[2]]);
+            const float a4 = cabs(sv[q_idx[3]]);
             const float l = logf(a1) + logf(a2) - logf(a3) - logf(a4);
-            const float r = (l - yv[k]) / ys[k];
+            const float r = (l - q_y) / q_s;
             s_ca += r * r;
-            dca[k] = 2.0f * r / ys[k];                     // d/dl of ((l - y)/s)^2
+            dca[k] = 2.0f * r / q_s;                       // d/dl of ((l - y)/s)^2
         }
     }
     // --- visibility / amplitude terms (zero weight in the shipped config), :453-464
