@@ -38,11 +38,6 @@
 #define LG2_YQ 6                  // float4 loads per thread and strip for the masked-out rows
 #define LG2_UNK_PARTS 16          // a batch-1 measurement: its masked-out rows are shared out
 
-#ifdef EXP_LG2_ALLTASK
-#define LG2_ALLTASK 1
-#else
-#define LG2_ALLTASK 0
-#endif
 #if defined(__HIPCC__)
 #define LG2_DEV __device__ __forceinline__
 // The value is declared modified: address arithmetic derived from it stays inside the loop
@@ -261,11 +256,11 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
     int t_ = tid;                                                                      \
     LG2_OPAQUE(t_);                                                                    \
     const int col = t_ & 31, g = t_ >> 5;                                              \
-    const bool a_task = LG2_ALLTASK || g < 12;                                         \
+    const bool a_task = g < 12;                                                        \
     const int bb = g < 12 ? g : 0;                                                     \
     const unsigned offA = (unsigned)(bb * R + col) * 4u; /* (row bb, column col), strip 0 */ \
     const unsigned offB = (unsigned)(g * R + col) * 4u;  /* (row g, column col) */     \
-    (void)offA; (void)offB;
+    (void)offA; (void)offB; (void)a_task;
 
     const int frame = ctx.block();
     if (frame >= nframes) return;
