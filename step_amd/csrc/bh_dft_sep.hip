@@ -120,7 +120,7 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
     const int nstrip = W >> 5, nblk = (H / 2) / SEP_U;
     float* eyl = lds;                         // [H][64]
     float* sred = lds + fwd_sred_offset(H, nstrip);   // [nstrip][64]
-    const int b = blockIdx.x, t = blockIdx.y;
+    const int t = blockIdx.x, b = blockIdx.y;   // ids in memory order; XCD c gets t % 8 == c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
 
@@ -180,12 +180,12 @@ extern "C" int bh_dft_fwd_sep(const float* ey_t, const float* ex_ri, int T, int 
     STEP_REQUIRE(lds <= 160 * 1024, "bh_dft_fwd_sep: %zu B of LDS needed (H=%d W=%d)", lds, H, W);
     if (H == 256 && W == 256) {
         step_allow_lds((const void*)k_dft_fwd_sep<256, 256>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_sep<256, 256>), dim3(B, T), dim3(SEP_THREADS), lds,
+        hipLaunchKernelGGL((k_dft_fwd_sep<256, 256>), dim3(T, B), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_t, ex_ri, x, vis_c64, flux, T, F, H, W, scale,
                            shift, clip_min);
     } else {
         step_allow_lds((const void*)k_dft_fwd_sep<0, 0>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_sep<0, 0>), dim3(B, T), dim3(SEP_THREADS), lds,
+        hipLaunchKernelGGL((k_dft_fwd_sep<0, 0>), dim3(T, B), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_t, ex_ri, x, vis_c64, flux, T, F, H, W, scale,
                            shift, clip_min);
     }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 8 : 2)) void k_dft_adj_sep(
     const int KP = (2 * F + 2) & ~1;          // k rows: Re f | Im f | flux | (zero pad)
     float* G = lds;                           // [KP][Hs]
     float* g2 = lds + KP * Hs;                // [2F + 2]: Re g | Im g | gflux | 0
-    const int b = blockIdx.x, t = blockIdx.y;
+    const int t = blockIdx.x, b = blockIdx.y;   // ids in memory order; XCD c gets t % 8 == c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const float cs = out_scale * (chain_scale ? chain_scale[b] : 1.f);
@@ -295,13 +295,13 @@ extern "C" int bh_dft_adj_sep(const float* ey_ri, const float* ex_ri, int T, int
         // let four workgroups share a CU, which keeps the matrix pipe fed while others build G
         const size_t lds = ((size_t)KP * 128 + 2 * F + 2) * sizeof(float);
         step_allow_lds((const void*)k_dft_adj_sep<256, 256, 2>, lds);
-        hipLaunchKernelGGL((k_dft_adj_sep<256, 256, 2>), dim3(B, T, 2), dim3(SEP_THREADS), lds,
+        hipLaunchKernelGGL((k_dft_adj_sep<256, 256, 2>), dim3(T, B, 2), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_ri, ex_ri, gvis_c64, gflux, chain_scale, grad, T,
                            F, H, W, out_scale);
     } else {
         const size_t lds = ((size_t)KP * H + 2 * F + 2) * sizeof(float);
         step_allow_lds((const void*)k_dft_adj_sep<0, 0, 1>, lds);
-        hipLaunchKernelGGL((k_dft_adj_sep<0, 0, 1>), dim3(B, T), dim3(SEP_THREADS), lds,
+        hipLaunchKernelGGL((k_dft_adj_sep<0, 0, 1>), dim3(T, B), dim3(SEP_THREADS), lds,
                            (hipStream_t)stream, ey_ri, ex_ri, gvis_c64, gflux, chain_scale, grad, T,
                            F, H, W, out_scale);
     }
