@@ -153,3 +153,39 @@ def test_latent_daps_mri_matches_reference(golden, dev):
         out = s.sample(model, t(d["z_start"], dev), op, mri_measurement(d).to(dev))
     assert not tape.n
     assert_close(out, d["result"], TRAJ_TOL, "LatentDAPS mri")
+
+
+@pytest.mark.parametrize("algo,momentum", [(0, 0.0), (1, 0.0), (1, 0.9), (2, 0.0)])
+def test_update_kernel_on_a_large_state(algo, momentum, dev):
+    """States of more than 8 x 256 KB are dealt to the XCDs in 256 KB chunks with the remainder
+    in plain order: every element is updated exactly once, against the formulas of
+    daps.py:93-104 / :135-144 / :210-223 in torch (bit for bit up to fma contraction)."""
+    import ctypes as C
+    from step_amd import _lib
+    n = 4 * (8 * 16384 * 3 + 16384 + 777)                  # three full rounds of chunks + a ragged tail
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x, g, xt, pr, eps, vel = (torch.randn(n, device=dev, generator=gen) for _ in range(6))
+    x0, v0 = x.clone(), vel.clone()
+    p = _lib.mcmc_params_t(0.7, 0.3, 1e-2, 0.1, 0.1414, momentum, 0.45, algo)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().mcmc_update(x.data_ptr(), vel.data_ptr(), g.data_ptr(), xt.data_ptr(),
+                                None if algo == 2 else pr.data_ptr(),
+                                None if algo == 2 else eps.data_ptr(), n, C.byref(p),
+                                flag.data_ptr(), _lib.stream_of(x))
+    _lib.check(rc, "mcmc_update")
+    f = lambda v: torch.tensor(v, dtype=torch.float32).item()
+    if algo == 2:
+        want = x0 - f(1e-2) * (g + (x0 - xt) * f(0.3))
+    else:
+        s = -g * f(0.7) + (xt - x0) * f(0.3) + pr
+        if algo == 0:
+            want = x0 + f(1e-2) * s + f(0.1414) * eps
+        else:
+            v = f(momentum) * v0 + f(0.1) * s + f(0.45) * eps
+            want = x0 + v * f(0.1)
+            if momentum != 0.0:
+                assert (vel - v).abs().max().item() <= 1e-5
+            else:
+                assert torch.equal(vel, v0)                    # momentum 0: the velocity is not stored
+    assert (x - want).abs().max().item() <= 1e-5
+    assert flag.item() == 0
