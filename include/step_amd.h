@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 2 since mri_loss_grad takes a 2*B*T workspace */
+int         step_abi_version(void);   /* 3 since mri_loss_grad takes `variant`, bh_weights_t `cphase_form` */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -165,6 +165,11 @@ typedef struct {               /* a measurement (BlackHoleObservation, blackhole
 typedef struct {               /* blackhole.py:175-180 (weights already multiplied by their dims) */
     float w_vis, w_amp, w_cp, w_camp, w_flux;
     int32_t normalize;         /* loss_normalize */
+    int32_t cphase_form;       /* how 1 - cos(d) of chi2_cphase (blackhole.py:472-474) is evaluated:
+                                * 0 = 2 sin^2(d/2): accurate to fp32 rounding for every d, what the
+                                *     fp64 evaluation of the reference formula converges to;
+                                * 1 = 1 - cosf(d): the reference's literal fp32 form, which cancels
+                                *     once a chain fits the data (d ~ 1e-3 keeps ~3 bits) */
 } bh_weights_t;
 
 /* Per-chain loss and its gradient w.r.t. vis / flux, from vis and flux of x01.
@@ -179,9 +184,11 @@ int bh_closure_loss(const float* vis_c64, const float* flux, int B,
 
 /* chi^2 of every data product for the evaluator (evaluate_chisq blackhole.py:671-699):
  * vis_scale[b][t] (may be NULL) multiplies frame t's visibilities first (the per-frame flux
- * alignment y_flux/x_flux is linear in the DFT).  chi2 [B][4] = vis, amp, cphase, logcamp, raw. */
+ * alignment y_flux/x_flux is linear in the DFT).  chi2 [B][4] = vis, amp, cphase, logcamp, raw.
+ * cphase_form as in bh_weights_t. */
 int bh_closure_chisq(const float* vis_c64, const float* vis_scale, int B, int F,
-                     const bh_tables_t* tab, const bh_meas_t* y, float* chi2, void* stream);
+                     const bh_tables_t* tab, const bh_meas_t* y, int cphase_form, float* chi2,
+                     void* stream);
 
 /* Full observation from vis (forward_from_vis blackhole.py:393-401): amp, sigma_amp
  * (= sigma broadcast), cphase, sigma_cphase, logcamp, sigma_logcamp.  sigma [n_vis]. */
@@ -208,11 +215,14 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
  * grad = chain_scale[b] * d loss[b] / d x  (autograd of the above; Appendix B "MRI").
  * grad may be NULL (loss only).  chain_scale may be NULL (=1).
  * loss_part: workspace float[2*B*T] (per-frame partial losses, then shares of the masked-out
- * rows' sum |y|^2 of a batch-1 measurement); loss [B]; loss_total (may be NULL): sum of loss[]. */
+ * rows' sum |y|^2 of a batch-1 measurement); loss [B]; loss_total (may be NULL): sum of loss[].
+ * variant: 0 = choose by mask (the software-pipelined kernel when every mask frame keeps <= 64
+ * rows, i.e. every shipped mode), 1 = first-generation kernel (any mask; cross-checks),
+ * 2 = pipelined kernel (STEP_E_INVALID if a mask frame keeps more than 64 rows). */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
-                  const float* chain_scale, float* loss_part, float* loss, float* loss_total,
-                  float* grad, void* stream);
+                  const float* chain_scale, int variant, float* loss_part, float* loss,
+                  float* loss_total, float* grad, void* stream);
 
 /* ------------------------------------------------------------------ MCMC state update */
 

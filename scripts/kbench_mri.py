@@ -1,5 +1,5 @@
 """MRI step timing at B = 32, 64, 256 (median of 20 event-timed launches).
-usage: python scripts/kbench_mri.py [lib.so]     (STEP_MRI_KERNEL=1 pins the first-generation kernel)"""
+usage: python scripts/kbench_mri.py [lib.so] [variant]     (variant 1 pins the first-generation kernel)"""
 import sys, os, torch
 sys.path.insert(0, '.')
 if len(sys.argv) > 1:
@@ -7,9 +7,11 @@ if len(sys.argv) > 1:
 from step_amd.forward_operator import get_operator
 dev = 'cuda:0'
 tag = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else 'libstep_amd.so'
-tag += ' v' + os.environ.get('STEP_MRI_KERNEL', '2')
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tag += ' v%d' % variant
 for mode, yb in (("same_mask", 1), ("split_mask", 1), ("same_mask", 0)):
     op = get_operator("mri", acc_factor=6, mode=mode, resolution=192, frames=12, num_acs_lines=24)
+    op.kernel_variant = variant
     for B in (32, 64, 256):
         x = torch.randn(B, 12, 2, 192, 192, device=dev); y = op(torch.randn(yb or B, 12, 2, 192, 192, device=dev))
         for _ in range(3): op.gradient(x, y)

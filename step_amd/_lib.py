@@ -35,7 +35,7 @@ class bh_meas_t(C.Structure):
 
 class bh_weights_t(C.Structure):
     _fields_ = [("w_vis", c_f), ("w_amp", c_f), ("w_cp", c_f), ("w_camp", c_f), ("w_flux", c_f),
-                ("normalize", C.c_int32)]
+                ("normalize", C.c_int32), ("cphase_form", C.c_int32)]
 
 
 class mcmc_params_t(C.Structure):
@@ -67,13 +67,13 @@ SIGNATURES = {
     "bh_closure_loss": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
                               C.POINTER(bh_weights_t), c_p, c_p, c_p, c_p, c_p]),
     "bh_closure_chisq": (c_i, [c_p, c_p, c_i, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
-                               c_p, c_p]),
+                               c_i, c_p, c_p]),
     "bh_closure_observe": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), c_p, c_p, c_p, c_p, c_p,
                                  c_p, c_p]),
     "mri_forward": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_adjoint": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
-    "mri_loss_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p,
-                            c_p, c_p]),
+    "mri_loss_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p,
+                            c_p, c_p, c_p]),
     "mcmc_update": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_p]),
 }
 

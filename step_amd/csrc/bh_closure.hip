@@ -28,10 +28,12 @@ __device__ __forceinline__ float2 cdir(float2 v, int conj) {   // blackhole.py:3
 }
 __device__ __forceinline__ float cabs(float2 v) { return hypotf(v.x, v.y); }
 
-// 1 - cos(d) as 2 sin^2(d/2): the reference's fp32 (1 - cos) cancels catastrophically once the
-// chain fits the data (d ~ 1e-3 leaves ~3 significant bits); this form stays accurate to fp32
-// rounding and is what the fp64 evaluation of the reference formula converges to.
-__device__ __forceinline__ float one_minus_cos(float d) {
+// 1 - cos(d), bh_weights_t::cphase_form.  Form 0, 2 sin^2(d/2): the reference's fp32 (1 - cos)
+// cancels catastrophically once the chain fits the data (d ~ 1e-3 leaves ~3 significant bits);
+// this form stays accurate to fp32 rounding and is what the fp64 evaluation of the reference
+// formula converges to.  Form 1: the reference's literal expression (blackhole.py:473).
+__device__ __forceinline__ float one_minus_cos(float d, int form) {
+    if (form == 1) return 1.0f - cosf(d);
     const float s = sinf(0.5f * d);
     return 2.0f * s * s;
 }
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(CLL_THREADS) void k_closure_loss(
             const float phi = atan2f(p.y, p.x);
             const float d = t_y - phi;
             const float is2 = 1.0f / (t_s * t_s);
-            s_cp += one_minus_cos(d) * is2;
+            s_cp += one_minus_cos(d, a.w.cphase_form) * is2;
             dcp[k] = -sinf(d) * is2;                       // d/dphi of (1 - cos(y - phi))/s^2
         }
     }
@@ -300,6 +302,7 @@ extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
     if (int rc = check_tables("bh_closure_loss", tab)) return rc;
     STEP_REQUIRE((gvis_c64 == nullptr) == (gflux == nullptr), "bh_closure_loss: gvis and gflux go together");
     STEP_REQUIRE(y->batch == 1 || y->batch == B, "bh_closure_loss: measurement batch %d vs B=%d", y->batch, B);
+    STEP_REQUIRE(w->cphase_form == 0 || w->cphase_form == 1, "bh_closure_loss: cphase_form %d", w->cphase_form);
     STEP_REQUIRE(!(w->w_cp > 0) || (tab->n_tri > 0 && y->cphase && y->sigma_cphase), "bh_closure_loss: cphase data missing");
     STEP_REQUIRE(!(w->w_camp > 0) || (tab->n_quad > 0 && y->logcamp && y->sigma_logcamp), "bh_closure_loss: logcamp data missing");
     STEP_REQUIRE(!(w->w_vis > 0) || (y->vis_c64 && y->sigma_vis), "bh_closure_loss: vis data missing");
@@ -315,9 +318,7 @@ extern "C" int bh_closure_loss(const float* vis_c64, const float* flux, int B,
     // the kernel is latency-bound and B workgroups leave most CUs idle: split the backward gather
     // of a chain over several workgroups while the grid stays within one round
     int parts = 1;
-#ifndef CLL_PARTS
-#define CLL_PARTS 4
-#endif
+    constexpr int CLL_PARTS = 4;
     if (gvis_c64) while (parts < CLL_PARTS && B * parts * 2 <= 256) parts *= 2;
     if (staged <= 150 * 1024) {
         step_allow_lds((const void*)k_closure_loss<true>, staged);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_chisq(
             const float2 i2 = cdir(sv[a.tab.cp_index[3 * k + 1]], a.tab.cp_conj[3 * k + 1]);
             const float2 i3 = cdir(sv[a.tab.cp_index[3 * k + 2]], a.tab.cp_conj[3 * k + 2]);
             const float2 p = cmul(cmul(i1, i2), i3);
-            s_cp += one_minus_cos(yv[k] - atan2f(p.y, p.x)) / (ys[k] * ys[k]);
+            s_cp += one_minus_cos(yv[k] - atan2f(p.y, p.x), a.w.cphase_form) / (ys[k] * ys[k]);
         }
     }
     if (a.y.logcamp && a.y.sigma_logcamp) {
@@ -401,13 +402,13 @@ __global__ __launch_bounds__(CL_THREADS) void k_closure_chisq(
 }
 
 extern "C" int bh_closure_chisq(const float* vis_c64, const float* vis_scale, int B, int F,
-                                const bh_tables_t* tab, const bh_meas_t* y, float* chi2,
-                                void* stream) {
+                                const bh_tables_t* tab, const bh_meas_t* y, int cphase_form,
+                                float* chi2, void* stream) {
     STEP_REQUIRE(vis_c64 && y && chi2 && B > 0 && F > 0, "bh_closure_chisq: null pointer / sizes");
     if (int rc = check_tables("bh_closure_chisq", tab)) return rc;
     STEP_REQUIRE(tab->n_vis == tab->T * F, "bh_closure_chisq: n_vis != T*F");
     STEP_REQUIRE(y->batch == 1 || y->batch == B, "bh_closure_chisq: measurement batch %d vs B=%d", y->batch, B);
-    ClosureArgs a{*tab, *y, bh_weights_t{0, 0, 0, 0, 0, 0}};
+    ClosureArgs a{*tab, *y, bh_weights_t{0, 0, 0, 0, 0, 0, cphase_form}};
     const size_t lds = (2 * (size_t)tab->n_vis + 16) * sizeof(float);
     step_allow_lds((const void*)k_closure_chisq, lds);
     hipLaunchKernelGGL(k_closure_chisq, dim3(B), dim3(CL_THREADS), lds, (hipStream_t)stream,

@@ -41,18 +41,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define S3_THREADS 512
-#ifndef S3_RING
 #define S3_RING 4
-#endif
-// chain handled in iteration `it` by chain group g of gx: blocked (g * cpw + it) or, with
-// EXP3_RR, dealt round-robin (g + it * gx: all workgroups sweep the batch as one front)
-#ifdef EXP3_RR
-#define S3_CHAIN(it) (grp + (it) * ngrp)
-#define S3_NIT() ((B - grp + ngrp - 1) / ngrp)
-#else
+// chain handled in iteration `it` by chain group grp: blocked (dealing the chains round-robin,
+// all workgroups sweeping the batch as one front, measured the same: DESIGN.md section 5)
 #define S3_CHAIN(it) (grp * cpw + (it))
 #define S3_NIT() min(cpw, B - grp * cpw)
-#endif
 #define S3_GCH 64          // adjoint: chains whose g is staged in LDS at a time
 #define S3_GROW 68         // floats per staged chain: 32 x (re, im), flux, pad to 16 bytes
 
@@ -75,15 +68,7 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
     }
 }
 
-#ifndef EXP3_NOMFMA
 #define S3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0)
-#else   // timing experiment: no matrix work, operands still consumed
-__device__ __forceinline__ f32x16 s3_fake(u32x4 a, u32x4 b, f32x16 c) {
-    c[0] += __uint_as_float((a[0] ^ b[0]) + (a[1] ^ b[1]) + (a[2] ^ b[2]) + (a[3] ^ b[3]));
-    return c;
-}
-#define S3_MFMA(a, b, c) s3_fake(a, b, c)
-#endif
 
 // the six plane products of one operand pair: corrections into sm, leading term into mn
 #define S3_SIX(ah, am, al, bh, bm, bl, sm, mn)                  \
@@ -154,8 +139,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     static_assert(NKB % R == 0, "ring must divide the block count");
     u32x4* eyp = lds4;
     float* sred = (float*)(lds4 + NKB * 384);
-    const int t = blockIdx.x % T, grp = blockIdx.x / T, ngrp = gridDim.x / T;   // s3_grid: why a 1-D grid
-    (void)ngrp;
+    const int t = blockIdx.x % T, grp = blockIdx.x / T;      // s3_grid: why a 1-D grid
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n_it = S3_NIT();
@@ -351,8 +335,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
     u32x4* eyp = lds4;
     float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
-    const int t = blockIdx.x % T, grp = blockIdx.x / T, ngrp = gridDim.x / T;   // s3_grid: why a 1-D grid
-    (void)ngrp;
+    const int t = blockIdx.x % T, grp = blockIdx.x / T;      // s3_grid: why a 1-D grid
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n_it = S3_NIT();
@@ -381,11 +364,8 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         u32x4* dst = eyp + (((part * 2 + kb) * 3) * 2 + hh) * HH + y;
         dst[0] = p0; dst[2 * HH] = p1; dst[4 * HH] = p2;
     }
-#ifdef EXP3_NT_STORE
-#define S3_STG(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#else
+    // plain stores: non-temporal ones were 5 % slower here and in the step
 #define S3_STG(ptr, v) (*(ptr) = (v))
-#endif
     const u32x4* ap = eyp + h * HH + li;
     // g of up to S3_GCH chains goes through LDS: a global load of the next chain's g inside the
     // chain loop would be waited for with vmcnt(0) -- loads and stores share that counter, in

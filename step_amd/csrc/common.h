@@ -13,6 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // thread-local error text behind step_last_error()
 void step_set_error(const char* fmt, ...);
 
+// body of mri_loss_grad (mri_fft.hip), shared with mri_loss_grad_static (mri_noalloc.hip)
+int mri_loss_grad_impl(const char* who, const float* x, const float* y, int y_batch, int B, int T,
+                       int R, const int32_t* rows, const int32_t* nrows, int mask_frames,
+                       int max_rows, const float* chain_scale, int variant, float* loss_part,
+                       float* loss, float* loss_total, float* grad, hipStream_t s);
+
 #define STEP_REQUIRE(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

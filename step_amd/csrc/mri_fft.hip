@@ -21,16 +21,6 @@
 #include "fft_small.h"
 #include "mri_lg2.h"
 
-#ifdef EXP_MRI_TIMING   // experiment builds only: phase timestamps of workgroup 0
-__device__ unsigned long long g_mri_t[16];
-#define MRI_TICK(i) { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_mri_t[i] = wall_clock64(); }
-extern "C" int mri_debug_timing(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mri_t), sizeof(unsigned long long) * 16);
-}
-#else
-#define MRI_TICK(i)
-#endif
-
 #define MRI_R 192
 #define MRI_THREADS 512
 #define MRI_SW 32                 // strip width (columns)
@@ -69,9 +59,6 @@ __device__ __forceinline__ float sgn(int k) { return (k & 1) ? -1.f : 1.f; }
 // keeps its 12 outputs in registers and writes only the kept k_y rows of the current row group,
 // sign-folded, straight into the row buffer: Rk[j][strip*32+col] = (-1)^ky X[ky][col].
 __device__ __forceinline__ void strip_fft_fwd(const MriLds& L, int strip, int g0, int nk) {
-#ifdef EXP_MRI_NOFFT
-    return;
-#endif
     const int tid = threadIdx.x, col = tid & 31;
     if (tid < 12 * 32) {
         const int bb = tid >> 5;
@@ -116,9 +103,7 @@ __device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0
             const int j = L.rowpos[12 * a + bb] - g0;
             v[a] = (j >= 0 && j < nk) ? L.Rk[(size_t)j * MRI_RS + strip * MRI_SW + col] : c_make(0.f, 0.f);
         }
-#ifndef EXP_MRI_NOFFT
         fft192_pass_a<1>(v, bb, L.tw);
-#endif
 #pragma unroll
         for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * MRI_SW + col] = v[c];
     }
@@ -128,9 +113,7 @@ __device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0
         cf32 v[12];
 #pragma unroll
         for (int b = 0; b < 12; ++b) v[b] = L.S[(12 * c + b) * MRI_SW + col];
-#ifndef EXP_MRI_NOFFT
         fft192_pass_b<1>(v);
-#endif
 #pragma unroll
         for (int d = 0; d < 12; ++d) {
             const int g = (c + 16 * d) * MRI_R + strip * MRI_SW + col;
@@ -144,9 +127,6 @@ __device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0
 // FFT along x of the nk kept rows Rk[nk][204], in place, natural order.
 template <int SIGN>
 __device__ __forceinline__ void rows_fft_x(const MriLds& L, int nk) {
-#ifdef EXP_MRI_NOFFT
-    return;
-#endif
     const int tid = threadIdx.x;
     for (int e = tid; e < nk * 12; e += MRI_THREADS) {
         const int j = e / 12, bb = e - 12 * j;
@@ -243,7 +223,6 @@ __device__ __forceinline__ void forward_rows(const MriLds& L, const float* __res
                     acc += yq[i].x * yq[i].x + yq[i].y * yq[i].y + yq[i].z * yq[i].z + yq[i].w * yq[i].w;
         }
     }
-    MRI_TICK(3)
     rows_fft_x<-1>(L, nk);
 }
 
@@ -319,7 +298,6 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
 __device__ __forceinline__ void adjoint_rows(const MriLds& L, const int* __restrict__ rowlist,
                                              int g0, int nk, float* __restrict__ dst) {
     rows_fft_x<1>(L, nk);
-    MRI_TICK(6)
     for (int strip = 0; strip < MRI_R / MRI_SW; ++strip)
         strip_fft_inv(L, strip, g0, nk, dst, dst + MRI_R * MRI_R, g0 != 0);
 }
@@ -341,11 +319,9 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
     const float* yr = y + ((size_t)(y_batch > 1 ? b : 0) * T + t) * fsz;
     const float* yi = yr + MRI_R * MRI_R;
     const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
-    MRI_TICK(0)
     cf32 pre[MRI_NP];
     load_strip(xr, xi, 0, pre);                        // in flight during the table set-up
     load_tables(L, rowlist, nk_total);
-    MRI_TICK(1)
 
     // rows outside the mask are summed inside forward_rows; a frame with no kept row does it here
     float acc = 0.f;
@@ -368,7 +344,6 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
         const int nk = min(nkc, nk_total - g0);
         if (g0) load_strip(xr, xi, 0, pre);
         forward_rows(L, xr, xi, g0, nk, pre, g0 == 0 ? yr : nullptr, MRI_R - nk_total, acc);
-        MRI_TICK(4)
         // residual, loss, adjoint input 2 * (-1)^(ky+kx) * r  (the row sign is already in Rk)
 #pragma unroll 4
         for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
@@ -384,9 +359,7 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
             L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
         }
         __syncthreads();
-        MRI_TICK(5)
         if (grad) adjoint_rows(L, rowlist, g0, nk, grad + (size_t)frame * fsz);
-        MRI_TICK(7)
     }
     const float tot = block_sum(acc, L.red);
     if (tid == 0) loss_part[frame] = tot;
@@ -400,13 +373,9 @@ struct Lg2DevCtx {
     __device__ __forceinline__ int nblocks() const { return gridDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ float* lds() const { return lds_; }
-    // experiment builds only (EXP_MRI_TIMING): phase timestamps of workgroup 0
-    __device__ __forceinline__ void tick(int i, int frame) const {
-#ifdef EXP_MRI_TIMING
-        __syncthreads();
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_mri_t[i] = wall_clock64();
-#endif
-    }
+    // phase marker of the body: a no-op here (scripts/probes/mri_timing.hip builds the body over
+    // a context that records timestamps)
+    __device__ __forceinline__ void tick(int, int) const {}
     __device__ __forceinline__ cf32 cos_sin_2pi_over_192(int e) const {
         float sn, cn;
         sincospif((float)e * (1.0f / 96.0f), &sn, &cn);
@@ -424,16 +393,6 @@ __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2(
     Lg2DevCtx ctx{lds};
     lg2_body<YQ>(ctx, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
                  loss_part, unk_part, grad);
-}
-
-// STEP_MRI_KERNEL=1 pins the first-generation kernel (experiments, cross-checks in the tests)
-static int mri_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("STEP_MRI_KERNEL");
-        v = (e && e[0] == '1') ? 1 : 2;
-    }
-    return v;
 }
 
 // ------------------------------------------------------------------------------- adjoint only
@@ -551,18 +510,24 @@ extern "C" int mri_adjoint(const float* g, int B, int T, int R, const int32_t* r
     return STEP_OK;
 }
 
-extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
-                             const int32_t* rows, const int32_t* nrows, int mask_frames,
-                             int max_rows, const float* chain_scale, float* loss_part, float* loss,
-                             float* loss_total, float* grad, void* stream) {
-    STEP_REQUIRE(x && y && loss_part && loss, "mri_loss_grad: null pointer");
-    STEP_REQUIRE(y_batch == 1 || y_batch == B, "mri_loss_grad: measurement batch %d vs B=%d", y_batch, B);
-    if (int rc = mri_check("mri_loss_grad", B, T, R, rows, nrows, mask_frames)) return rc;
+// Shared body of mri_loss_grad and mri_loss_grad_static.  variant: 0 = pick by mask (pipelined
+// kernel when every mask frame fits one row buffer), 1 = first-generation kernel, 2 = pipelined
+// kernel (an error if the mask does not fit).
+int mri_loss_grad_impl(const char* who, const float* x, const float* y, int y_batch, int B,
+                              int T, int R, const int32_t* rows, const int32_t* nrows,
+                              int mask_frames, int max_rows, const float* chain_scale, int variant,
+                              float* loss_part, float* loss, float* loss_total, float* grad,
+                              hipStream_t s) {
+    STEP_REQUIRE(x && y && loss_part && loss, "%s: null pointer", who);
+    STEP_REQUIRE(y_batch == 1 || y_batch == B, "%s: measurement batch %d vs B=%d", who, y_batch, B);
+    STEP_REQUIRE(variant >= 0 && variant <= 2, "%s: variant %d (0 auto, 1 first generation, 2 pipelined)", who, variant);
+    if (int rc = mri_check(who, B, T, R, rows, nrows, mask_frames)) return rc;
+    STEP_REQUIRE(variant != 2 || max_rows <= LG2_NKC_MAX,
+                 "%s: the pipelined kernel takes masks of <= %d kept rows (got %d)", who, LG2_NKC_MAX, max_rows);
     const int nkc = pick_nkc(max_rows);
-    hipStream_t s = (hipStream_t)stream;
     float* unk = loss_part + (size_t)B * T;              // second part of the workspace
     int n_unk = 0;
-    if (max_rows <= LG2_NKC_MAX && mri_variant() == 2) {
+    if (max_rows <= LG2_NKC_MAX && variant != 1) {
         // every mask frame fits one row buffer: pipelined kernel
         const size_t lds = lg2_lds_bytes(nkc);
         const int nframes = B * T;
@@ -584,8 +549,17 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
         hipLaunchKernelGGL(k_mri_loss_grad, dim3(B * T), dim3(MRI_THREADS), lds, s, x, y, y_batch,
                            rows, nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
     }
-    STEP_CHECK_LAUNCH("mri_loss_grad");
+    STEP_CHECK_LAUNCH(who);
     hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss, loss_total);
-    STEP_CHECK_LAUNCH("mri_loss_finish");
+    STEP_CHECK_LAUNCH(who);
     return STEP_OK;
+}
+
+extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
+                             const int32_t* rows, const int32_t* nrows, int mask_frames,
+                             int max_rows, const float* chain_scale, int variant, float* loss_part,
+                             float* loss, float* loss_total, float* grad, void* stream) {
+    return mri_loss_grad_impl("mri_loss_grad", x, y, y_batch, B, T, R, rows, nrows, mask_frames,
+                              max_rows, chain_scale, variant, loss_part, loss, loss_total, grad,
+                              (hipStream_t)stream);
 }

@@ -22,7 +22,7 @@ void step_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* step_last_error(void) { return g_err; }
-extern "C" int step_abi_version(void) { return 2; }   // 2: mri_loss_grad workspace is 2*B*T floats
+extern "C" int step_abi_version(void) { return 3; }   // 3: mri_loss_grad takes `variant`, bh_weights_t has `cphase_form`
 
 #define REQ(cond, ...)                      \
     do {                                    \

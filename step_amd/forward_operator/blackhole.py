@@ -11,6 +11,11 @@ Three kernel paths compute the same contraction vis = A_vis x:
   * ``dense`` -- an arbitrary complex A_vis tensor (``from_tensors``), packed once for MFMA.
 The set-up that the reference delegates to ehtim (array file -> uv, sigma, closure sets) is
 done by ``step_amd.eht_lite`` (PARITY UNPINNED, see there); pass ``obs_table=`` to supply it.
+
+``cphase_form`` names how the closure-phase chi^2 evaluates ``1 - cos(d)`` (blackhole.py:472-474):
+``'stable'`` (default) as ``2 sin^2(d/2)``, which keeps fp32 accuracy when a chain already fits the
+data (the reference's own fp32 value is rounding noise there, ~1e-2 relative once chi^2 << 1);
+``'reference'`` evaluates the reference's literal ``1 - cos(d)`` in fp32.
 """
 import ctypes as C
 import math
@@ -24,6 +29,9 @@ from .base import Operator, register_operator
 __all__ = ["BlackHoleObservation", "BlackHoleImagingTorch", "save_observation", "load_observation"]
 
 _NEG_INF = float("-inf")
+# how chi2_cphase evaluates 1 - cos(d) (bh_weights_t::cphase_form in include/step_amd.h):
+# 'stable' = 2 sin^2(d/2), 'reference' = the reference's literal fp32 1 - cos(d)
+_CPHASE_FORMS = {"stable": 0, "reference": 1}
 
 
 class BlackHoleObservation(object):
@@ -206,7 +214,7 @@ class BlackHoleImagingTorch(Operator):
     def __init__(self, array="configs/task/EHT2017.txt", imsize=256, w_vis=0, w_amp=0,
                  w_cphase=1, w_logcamp=1, w_flux=0.5, loss_normalize=True, num_frames=64,
                  ref_multiplier=1.0, device='cuda', obs_table=None, force_dense=False,
-                 dft='auto'):
+                 dft='auto', cphase_form='stable'):
         super().__init__(0)
         assert num_frames == 64, "num_frames should be 64"
         table = obs_table if obs_table is not None else eht_lite.eht_table(array)
@@ -221,7 +229,7 @@ class BlackHoleImagingTorch(Operator):
         cp_i, cp_c, ca_i, ca_c = self._closure_tables(table)
         ey, ex = eht_lite.ft_factors(uv, imsize, imsize, self.psize)
         self._init_common(T, F, imsize, imsize, sigma, cp_i, cp_c, ca_i, ca_c, w_vis, w_amp,
-                          w_cphase, w_logcamp, w_flux, loss_normalize)
+                          w_cphase, w_logcamp, w_flux, loss_normalize, cphase_form)
         sep_ok = (F <= 31 and imsize % 32 == 0 and imsize <= 512)
         assert dft in ("auto", "sep3", "sep", "dense"), dft
         if force_dense:
@@ -244,7 +252,7 @@ class BlackHoleImagingTorch(Operator):
     @classmethod
     def from_tensors(cls, A_vis, sigma, cp_index, cp_conjugate, camp_index, camp_conjugate,
                      imsize, w_vis=0, w_amp=0, w_cphase=1, w_logcamp=1, w_flux=0.5,
-                     loss_normalize=True, device='cuda', dft='auto'):
+                     loss_normalize=True, device='cuda', dft='auto', cphase_form='stable'):
         """Operator around a dense ``A_vis`` ([1,T,F,H*W] or [T,F,H*W] complex) and the
         reference's index tensors -- the attributes the reference keeps (blackhole.py:155-163).
         ``sigma`` is the per-visibility sigma already divided by ref_multiplier.
@@ -263,7 +271,8 @@ class BlackHoleImagingTorch(Operator):
         H, W = (imsize, imsize) if isinstance(imsize, int) else imsize
         assert H * W == HW
         self._init_common(T, F, H, W, sigma.float(), cp_index, cp_conjugate, camp_index,
-                          camp_conjugate, w_vis, w_amp, w_cphase, w_logcamp, w_flux, loss_normalize)
+                          camp_conjugate, w_vis, w_amp, w_cphase, w_logcamp, w_flux, loss_normalize,
+                          cphase_form)
         factors = None
         if dft != "dense" and F <= 31 and H % 32 == 0 and W % 32 == 0 and max(H, W) <= 512:
             factors = factor_A_vis(A, H, W)
@@ -308,7 +317,10 @@ class BlackHoleImagingTorch(Operator):
         return tuple(torch.from_numpy(a) for a in (cp_i, cp_c, ca_i, ca_c))
 
     def _init_common(self, T, F, H, W, sigma, cp_i, cp_c, ca_i, ca_c, w_vis, w_amp, w_cphase,
-                     w_logcamp, w_flux, loss_normalize):
+                     w_logcamp, w_flux, loss_normalize, cphase_form='stable'):
+        if cphase_form not in _CPHASE_FORMS:
+            raise ValueError("cphase_form must be 'stable' or 'reference', got %r" % (cphase_form,))
+        self.cphase_form = cphase_form
         dev = self.device
         self.T, self.F, self.H, self.W = T, F, H, W
         self.sigma = sigma.to(dev).contiguous()                           # [T*F]
@@ -354,7 +366,8 @@ class BlackHoleImagingTorch(Operator):
                                      tt["ca_ent"].data_ptr())
         self._weights = _lib.bh_weights_t(float(self.weight_vis), float(self.weight_amp),
                                           float(self.weight_cp), float(self.weight_camp),
-                                          float(self.weight_flux), int(bool(loss_normalize)))
+                                          float(self.weight_flux), int(bool(loss_normalize)),
+                                          _CPHASE_FORMS[cphase_form])
 
     def _init_sep(self, ey, ex):
         T, F, H, W, dev = self.T, self.F, self.H, self.W, self.device
@@ -602,7 +615,8 @@ class BlackHoleImagingTorch(Operator):
         meas, keep = self._meas(y)
         rc = _lib.lib().bh_closure_chisq(torch.view_as_real(vis).data_ptr(), scale.data_ptr(), B,
                                          self.F, C.byref(self._tab), C.byref(meas),
-                                         chi2.data_ptr(), _lib.stream_of(vis))
+                                         self._weights.cphase_form, chi2.data_ptr(),
+                                         _lib.stream_of(vis))
         _lib.check(rc, "bh_closure_chisq")
         results = {}
         for i, k in enumerate(('vis', 'amp', 'cphase', 'logcamp')):

@@ -79,6 +79,7 @@ class DynamicMRI(Operator):
         self._dev_tables = {}
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
+    kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined
     _unit_upstream = False   # set by LatentWrapper.gradient around its autograd.grad call
 
     def _tables(self, device):
@@ -135,7 +136,7 @@ class DynamicMRI(Operator):
         rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
                                       self.resolution, rows.data_ptr(), nrows.data_ptr(),
                                       self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
-                                      part.data_ptr(), loss.data_ptr(),
+                                      self.kernel_variant, part.data_ptr(), loss.data_ptr(),
                                       loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
         if t0 is not None:
             t1 = torch.cuda.Event(enable_timing=True)
