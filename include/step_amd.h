@@ -224,6 +224,20 @@ int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int
                   const float* chain_scale, int variant, float* loss_part, float* loss,
                   float* loss_total, float* grad, void* stream);
 
+/* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
+ * the reference.  Same arguments, kernels and results as mri_loss_grad(variant = 0); the
+ * 2*B*T-float workspace lives in a file-scope device array of the library instead
+ * (2 * STEP_MRI_STATIC_MAX_FRAMES floats = 256 KiB, held by every GPU the library runs on until
+ * the process ends).  B*T > STEP_MRI_STATIC_MAX_FRAMES -> STEP_E_INVALID.  The call allocates and
+ * frees nothing.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race on it -- serialise them or use mri_loss_grad. */
+#define STEP_MRI_STATIC_MAX_FRAMES 32768
+int mri_loss_grad_static(const float* x, const float* y, int y_batch, int B, int T, int R,
+                         const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
+                         const float* chain_scale, float* loss, float* loss_total, float* grad,
+                         void* stream);
+
 /* ------------------------------------------------------------------ MCMC state update */
 
 typedef struct {
