@@ -13,6 +13,13 @@ Inputs are resident in HBM before the timed region.  value = chain-steps / s ove
 
 Multi-GPU: chains are independent, so each rank runs its own B chains (weak scaling) with no
 data-path collective; the barrier + MAX-over-ranks timing is the only communication.
+``python bench.py --gpus N`` (N > 1, no torchrun environment) starts the N ranks itself: the
+parent makes no GPU call and runs ``python -m torch.distributed.run --nproc-per-node N bench.py ...``
+as a child process, passing its output and exit code on.
+
+Clock ramp: an idle MI355X runs its first ~15 ms of work 20 % below steady state.  Before the W
+warm-up steps the bench therefore issues untimed steps until ``--prewarm-ms`` (default 60) of
+wall time have passed; the JSON line reports it as ``prewarm_ms``.
 """
 import argparse
 import json
@@ -43,7 +50,29 @@ def parse():
     p.add_argument("--path", default="auto", choices=["auto", "sep3", "sep", "dense"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-reps", type=int, default=8)
+    p.add_argument("--prewarm-ms", type=float, default=60.0,
+                   help="untimed steps before the warm-up until this much wall time has passed (clock ramp)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="rank plumbing only (gloo, no GPU, no kernels): launch, barrier, MAX-reduce, JSON line")
+    p.add_argument("--no-small-batches", action="store_true",
+                   help="skip the extra B = 8 / B = 1 measurements of the default blackhole run")
     return p.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) as a child
+    torch.distributed.run.  This process has made no GPU call and makes none."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def measured_traffic(kernel, matches):
@@ -120,15 +149,40 @@ def cpu_baseline_mri(reps):
                 sample="%d x oracle gradient, B=8, 12x2x192x192, acc 6 / 24 ACS" % reps)
 
 
+def dry_run(a, rank, world):
+    """The multi-rank plumbing of main() without a GPU (tests/test_bench_spawn.py): rendezvous over
+    gloo, barrier, MAX over ranks of the per-rank time, one JSON line from rank 0."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps(dict(metric="dry run", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                              max_over_ranks=t.item(), dry_run=True)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_run:
+        return dry_run(a, rank, world)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.gpus != world and rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (a.gpus, world, world),
+                  file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # SURVEY 8d: blackhole B in {1, 8, 64} (config 4 runs 64 samples), MRI B in {1, 32, 256}
@@ -151,6 +205,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # untimed, disclosed pre-warm: leave the clock ramp of an idle GPU before anything is timed
+    t_pre = time.perf_counter()
+    prewarm_steps = 0
+    while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+        for _ in range(10):
+            op.gradient(x, y, return_loss=True)
+        torch.cuda.synchronize()
+        prewarm_steps += 10
+    prewarm_ms = (time.perf_counter() - t_pre) * 1e3
     for _ in range(a.warmup):
         op.gradient(x, y, return_loss=True)
     torch.cuda.synchronize()
@@ -176,6 +239,9 @@ def main():
 
     if rank == 0:
         kern = {k: float(np.mean(event_ms(v))) for k, v in prof.items()}
+        dtype = "f32"
+        if a.task == "blackhole" and op.path == "sep3":
+            dtype = "f32 (3xbf16 exact operand split on the bf16 MFMA, fp32 accumulate)"
         if a.task == "blackhole":
             T, F, HW = 64, 28, 256 * 256
             flop = 4.0 * T * F * HW * B                       # per direction per launch
@@ -216,7 +282,8 @@ def main():
         out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
                    unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=1e3 * dt / a.steps, higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
+                   vs_baseline=None, dtype=dtype, data="synthetic",
+                   prewarm_ms=prewarm_ms, prewarm_steps=prewarm_steps,
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)

@@ -1,0 +1,30 @@
+"""`python bench.py --gpus N` starts its own N ranks (the driver runs exactly that command): the
+rank plumbing -- spawn, rendezvous on 127.0.0.1, barrier, MAX over ranks, one JSON line from rank 0
+with n_gpus = N -- checked on the CPU with the gloo backend (--dry-run: no GPU, no kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["max_over_ranks"] == 2.0            # rank 1's value: the MAX went over both ranks
+
+
+def test_gpus_1_stays_in_process():
+    r = _run(["--gpus", "1", "--dry-run"])
+    assert r["n_gpus"] == 1 and r["max_over_ranks"] == 1.0
