@@ -155,14 +155,20 @@ def test_latent_daps_mri_matches_reference(golden, dev):
     assert_close(out, d["result"], TRAJ_TOL, "LatentDAPS mri")
 
 
+@pytest.mark.parametrize("chunked", [True, False])
 @pytest.mark.parametrize("algo,momentum", [(0, 0.0), (1, 0.0), (1, 0.9), (2, 0.0)])
-def test_update_kernel_on_a_large_state(algo, momentum, dev):
-    """States of more than 8 x 256 KB are dealt to the XCDs in 256 KB chunks with the remainder
-    in plain order: every element is updated exactly once, against the formulas of
-    daps.py:93-104 / :135-144 / :210-223 in torch (bit for bit up to fma contraction)."""
+def test_update_kernel_on_a_large_state(algo, momentum, chunked, dev):
+    """States whose launch is a multiple of 8 workgroups (in practice the 4096-workgroup cap:
+    more than 1 Mi float4, every pixel-space state) are dealt to the XCDs in 256 KB chunks with the
+    remainder in plain order; other sizes run the plain grid-stride loop.  Both paths: every
+    element is updated exactly once, against the formulas of daps.py:93-104 / :135-144 / :210-223
+    in torch (bit for bit up to fma contraction)."""
     import ctypes as C
     from step_amd import _lib
-    n = 4 * (8 * 16384 * 3 + 16384 + 777)                  # three full rounds of chunks + a ragged tail
+    # nine / three full rounds of eight chunks + one more chunk + a ragged tail
+    n = 4 * (8 * 16384 * (9 if chunked else 3) + 16384 + 777)
+    blocks = min((n // 4 + 255) // 256, 4096)              # the launch rule of mcmc_update
+    assert (blocks % 8 == 0) == chunked and n // 4 > 8 * 16384
     gen = torch.Generator(device=dev).manual_seed(5)
     x, g, xt, pr, eps, vel = (torch.randn(n, device=dev, generator=gen) for _ in range(6))
     x0, v0 = x.clone(), vel.clone()

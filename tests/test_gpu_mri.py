@@ -155,3 +155,27 @@ def test_fused_step_equals_forward_then_adjoint(dev):
     assert_close(g, 2.0 * op._launch_adjoint(r.contiguous()), RTOL, "gradient vs A^H residual")
     assert_close(op.loss(x, y), (r.double() ** 2).flatten(1).sum(-1), RTOL, "loss vs forward")
     assert_close(lsum, (r.double() ** 2).sum(), RTOL, "loss sum")
+
+
+@pytest.mark.parametrize("y_per_chain", [False, True])
+def test_bench_batch_256_against_the_oracle_on_a_subsample(y_per_chain, dev):
+    """B = 256 (bench.py's MRI batch: 12 rounds of workgroups on 256 CUs) is checked against the
+    oracle on a sub-sample of the chains -- first, last and a few in between, so that every round of
+    the grid and both measurement layouts (one for all chains / one per chain) are covered."""
+    B, pick = 256, [0, 1, 15, 16, 127, 200, 255]
+    op, orc = make_op("same_mask"), MRIOracle(6, "same_mask", 192, 12, 24)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
+    y = op(torch.randn(B if y_per_chain else 1, 12, 2, 192, 192, device=dev, generator=gen)) \
+        + 0.1 * torch.randn(B if y_per_chain else 1, 12, 2, 192, 192, device=dev, generator=gen)
+    grad, lsum = op.gradient(x, y, return_loss=True)
+    loss = op.loss(x, y)
+    xs = x[pick].cpu()
+    ys = y[pick].cpu() if y_per_chain else y.cpu()
+    g_ref = orc.gradient(xs, ys)
+    l_ref = orc.loss(xs, ys)
+    assert_close(loss[pick], l_ref, RTOL, "per-chain loss")
+    for i, b in enumerate(pick):
+        assert_close(grad[b], g_ref[i], RTOL, "gradient of chain %d" % b)
+    assert_close(lsum, loss.double().sum(), RTOL, "loss total")
+    assert torch.isfinite(grad).all()
