@@ -196,6 +196,43 @@ int bh_closure_observe(const float* vis_c64, const float* sigma, int B, const bh
                        float* amp, float* sigma_amp, float* cphase, float* sigma_cphase,
                        float* logcamp, float* sigma_logcamp, void* stream);
 
+/* ------------------------------------------------------------------ fused black-hole step
+ * One Langevin data step of the black-hole operator -- operator.gradient(x, y, return_loss=True),
+ * daps.py:100 -> blackhole.py:736-771 + base.py:43-49 -- in TWO launches instead of three: the
+ * closure stage rides in the DFT kernels (forward epilogue: per-frame closure terms and chi^2
+ * partial sums; adjoint prologue: chi^2 -> normalize_chisq -> g_vis by the incidence gather;
+ * bh_dft_sep3.hip).  Same arithmetic as bh_dft_fwd_sep3 -> bh_closure_loss -> bh_dft_adj_sep3
+ * except for the order in which the chi^2 terms are summed (per frame, then over frames).
+ * Preconditions (else STEP_E_INVALID; callers fall back to the three calls):
+ *   - the bh_dft_*_sep3 preconditions (bh_sep3_supported, bh_sep3_tables_ok);
+ *   - every triangle / quadrangle involves baselines of ONE frame and a frame has at most 64 of
+ *     each (bh_build_frame_closures succeeds) -- true for tables built by process_obs, whose
+ *     baseline keys include the time (blackhole.py:237-241);
+ *   - one measurement for all chains (y->batch == 1) and w_vis == w_amp == 0 (the shipped config). */
+
+/* frame_tab: HOST int32 [T][2][64][2]: for frame t, kind (0 triangles, 1 quadrangles), slot j:
+ * (closure id k or -1, packed local baseline indices 5 bits each + conjugate flags from bit 15). */
+int bh_build_frame_closures(const int64_t* cp_index, const int64_t* cp_conj, int64_t n_tri,
+                            const int64_t* camp_index, int64_t n_quad, int T, int F,
+                            int32_t* frame_tab);
+
+typedef struct {               /* device workspace of the fused step (caller-owned, any contents) */
+    float* vis_c64;            /* [B][T*F] complex: the visibilities of x (an output as well) */
+    float* flux;               /* [B][T] */
+    float* dcp;                /* [B][n_tri] */
+    float* dca;                /* [B][n_quad] */
+    float* S;                  /* [B][T][4], 16-byte aligned */
+} bh_step_ws_t;
+
+/* loss [B], chi2 [B][5] (may be NULL), loss_total (may be NULL) = sum of loss[],
+ * grad [B][T][H*W] = out_scale * chain_scale[b] * d loss[b] / d x' with x' = 0.5 x + 0.5
+ * (out_scale = 0.5 gives d loss / d x; chain_scale may be NULL). */
+int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri, int T, int F,
+                      int H, int W, const float* x, int B, const bh_tables_t* tab,
+                      const int32_t* frame_tab, const bh_meas_t* y, const bh_weights_t* w,
+                      const bh_step_ws_t* ws, const float* chain_scale, float out_scale,
+                      float* loss, float* chi2, float* loss_total, float* grad, void* stream);
+
 /* ------------------------------------------------------------------ dynamic MRI
  * x, y, out: [B][T][2][R][R] fp32 (channel 0 = Re, 1 = Im); R == 192.
  * rows: int32 [mask_frames][R] = kept k_y rows of each mask frame, ascending, padded with -1;

@@ -1,12 +1,14 @@
 """Black-hole step at small batches: per-kernel event times, eager step, graph-replayed step.
 usage: python scripts/kbench_small.py [B ...]"""
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from step_amd import eht_lite
 from step_amd.forward_operator import BlackHoleImagingTorch
 dev = torch.device('cuda:0')
 tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
 op = BlackHoleImagingTorch(imsize=256, w_flux=0.26, ref_multiplier=0.001, device=dev, obs_table=tab)
+import os
+op.fused_step = os.environ.get('FUSED', '1') == '1'
 y = op(torch.rand(1, 64, 1, 256, 256, device=dev) * 2 - 1)
 for B in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16, 64]:
     x = torch.rand(B, 64, 1, 256, 256, device=dev) * 2 - 1

@@ -38,6 +38,10 @@ class bh_weights_t(C.Structure):
                 ("normalize", C.c_int32), ("cphase_form", C.c_int32)]
 
 
+class bh_step_ws_t(C.Structure):
+    _fields_ = [("vis_c64", c_p), ("flux", c_p), ("dcp", c_p), ("dca", c_p), ("S", c_p)]
+
+
 class mcmc_params_t(C.Structure):
     _fields_ = [("inv_tau2", c_f), ("inv_sigma2", c_f), ("lr", c_f), ("sqrt_lr", c_f),
                 ("sqrt_2lr", c_f), ("momentum", c_f), ("noise_scale", c_f), ("algo", C.c_int32)]
@@ -64,6 +68,10 @@ SIGNATURES = {
     "bh_dft_fwd_sep3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_f, c_f, c_p, c_p, c_p]),
     "bh_dft_adj_sep3": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_i,
                               c_p, c_p]),
+    "bh_build_frame_closures": (c_i, [c_p, c_p, c_i64, c_p, c_i64, c_i, c_i, c_p]),
+    "bh_loss_grad_sep3": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, C.POINTER(bh_tables_t), c_p,
+                                C.POINTER(bh_meas_t), C.POINTER(bh_weights_t), C.POINTER(bh_step_ws_t),
+                                c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "bh_closure_loss": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
                               C.POINTER(bh_weights_t), c_p, c_p, c_p, c_p, c_p]),
     "bh_closure_chisq": (c_i, [c_p, c_p, c_i, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),

@@ -36,6 +36,7 @@
 //   (w), splits w into planes in registers, and produces two mirrored 32x32 output tiles from
 //   24 MFMAs; no barrier and no vector load in the chain loop.
 #include "common.h"
+#include "closure_math.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -124,16 +125,79 @@ extern "C" int bh_sep3_tables_ok(const float* ey_ri_host, int T, int H) {
     return 1;
 }
 
+// ------------------------------------------------------------------------------- fused step
+// bh_loss_grad_sep3 runs the whole Langevin data step -- DFT, closure quantities, chi^2, loss,
+// their backward, DFT adjoint -- in TWO launches: the closure stage has no kernel of its own.
+//   forward epilogue: the frame's closure phases / log closure amplitudes only involve the frame's
+//     own visibilities (process_obs keys every baseline by its time, blackhole.py:237-241), so the
+//     wave that sums the strips goes on to evaluate them (wave 0 the triangles, wave 1 the
+//     quadrangles; one closure per lane, table entries and the batch-1 measurement held in
+//     registers for all chains: nothing is loaded in the chain loop), writes each closure's
+//     derivative term d/dphi, d/dl and the frame's partial chi^2 sums S[b][t];
+//   adjoint prologue: per chain, sum S over the frames -> chi^2 -> e'(chi^2) (normalize_chisq) ->
+//     the factors of the backward; the frame's g_vis follows from the derivative terms by the
+//     same incidence gather as in k_closure_loss and goes straight into the LDS staging of g.
+//     Workgroup 0 also evaluates every chain's loss and their total.
+struct S3FusedFwd {
+    const int32_t* ftab;      // [T][2][64][2]: (closure id k or -1, packed legs) -- bh_build_frame_closures
+    const float* y_cp;        // measurement (batch 1): cphase, sigma_cphase, logcamp, sigma_logcamp, flux
+    const float* s_cp;
+    const float* y_ca;
+    const float* s_ca;
+    const float* y_fl;
+    float* dcp;               // [B][Kcp]  d/dphi of (1 - cos(y - phi)) / s^2
+    float* dca;               // [B][Kca]  d/dl of ((l - y) / s)^2
+    float* S;                 // [B][T][4] partial sums: cphase, logcamp, flux^2 residual, unused
+    int Kcp, Kca, cphase_form;
+};
+
+struct S3FusedAdj {
+    const float2* vis;        // [B][T*F]
+    const float* flux;        // [B][T]
+    const float* S;
+    const float* dcp;
+    const float* dca;
+    const int32_t* cp_ptr;    // incidence CSR over the T*F baselines (bh_build_incidence)
+    const int32_t* cp_ent;
+    const int32_t* ca_ptr;
+    const int32_t* ca_ent;
+    const float* y_fl;
+    float w_cp, w_camp, w_flux;
+    int normalize, Kcp, Kca;
+    float* loss;              // [B]
+    float* chi2;              // [B][5] or null
+    float* total;             // sum of loss[] or null
+};
+
+// chi^2 sums of one chain -> loss and the backward factors (same order of operations as
+// k_closure_loss).  s_* are the sums over all frames.
+__device__ __forceinline__ void s3_chain_factors(const S3FusedAdj& z, int T, float s_cp, float s_ca,
+                                                 float s_fl, float& f_cp, float& f_ca, float& L,
+                                                 float& chi_cp, float& chi_ca, float& chi_fl) {
+    chi_cp = z.w_cp > 0.f ? 2.0f * s_cp / z.Kcp : 0.f;
+    chi_ca = z.w_camp > 0.f ? s_ca / z.Kca : 0.f;
+    chi_fl = z.w_flux > 0.f ? s_fl / T : 0.f;
+    float e_cp = 0.f, d_cp = 0.f, e_ca = 0.f, d_ca = 0.f;
+    if (z.w_cp > 0.f) fold(chi_cp, z.normalize, e_cp, d_cp);
+    if (z.w_camp > 0.f) fold(chi_ca, z.normalize, e_ca, d_ca);
+    L = 0.f;
+    if (z.w_cp > 0.f) L += z.w_cp * e_cp;
+    if (z.w_camp > 0.f) L += z.w_camp * e_ca;
+    if (z.w_flux > 0.f) L += z.w_flux * chi_fl;
+    f_cp = z.w_cp * d_cp * 2.0f / z.Kcp;
+    f_ca = z.w_camp * d_ca / z.Kca;
+}
+
 // ------------------------------------------------------------------------------- forward
 // LDS: ey planes, 16-byte units [((kb*2 + part)*3 + plane)*2 + h][32 rows f] (kb = block of 16
 // rows of the upper half, part 0 = Re ey, 1 = Im ey): the A fragment of lane (f, h) for
 // k = 16 kb + 8 h + 0..7 is one ds_read_b128, consecutive lanes read consecutive units.
 // Then sred [parity][2 * strips][64].
-template <int H, int W, int R, bool CLIP>
+template <int H, int W, int R, bool CLIP, bool FUSED>
 __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
     const float* __restrict__ ey_t, const float* __restrict__ ex_ri, const float* __restrict__ x,
     float* __restrict__ vis, float* __restrict__ flux, int T, int F, int B, int cpw, float scale,
-    float shift, float clip_min) {
+    float shift, float clip_min, S3FusedFwd fz) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
     constexpr int NKB = H / 32, NSTRIP = W / 32, NPART = 2 * NSTRIP;
     static_assert(NKB % R == 0, "ring must divide the block count");
@@ -155,21 +219,21 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
         exv_r[r] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
         exv_i[r] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
     }
-
-#pragma unroll
-    for (int u = tid; u < (H / 16) * 64; u += S3_THREADS) {
-        const int col = u & 63, yg = u >> 6;                 // col = part*32 + f, yg = 2 kb + h
-        const float* src = ey_t + ((size_t)t * H + yg * 8) * 64 + col;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[j * 64];
-        u32x4 p0, p1, p2;
-        split3(v, p0, p1, p2);
-        const int kb = yg >> 1, hh = yg & 1, part = col >> 5, f = col & 31;
-        u32x4* dst = eyp + (((kb * 2 + part) * 3) * 2 + hh) * 32 + f;
-        dst[0] = p0; dst[64] = p1; dst[128] = p2;
+    // FUSED: this lane's closure of frame t (wave 0: triangle `lane`, wave 1: quadrangle `lane`)
+    // and its measurement, in registers for all chains (a load in the chain loop would drain the ring)
+    int ck = -1, cpk = 0;
+    float cy = 0.f, cis = 0.f, yfl = 0.f;
+    if (FUSED && strip < 2) {
+        const int32_t* e = fz.ftab + (((size_t)t * 2 + strip) * 64 + lane) * 2;
+        ck = (strip == 0 ? fz.y_cp : fz.y_ca) ? e[0] : -1;   // a term with zero weight: no closures
+        cpk = e[1];
+        if (ck >= 0) {
+            cy = (strip == 0 ? fz.y_cp : fz.y_ca)[ck];
+            const float sg = (strip == 0 ? fz.s_cp : fz.s_ca)[ck];
+            cis = strip == 0 ? 1.0f / (sg * sg) : 1.0f / sg;
+        }
+        yfl = fz.y_fl[t];
     }
-    __syncthreads();
 
     const u32x4* ap = eyp + h * 32 + li;
     const size_t frame = (size_t)H * W;
@@ -223,6 +287,22 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // the frame's ey planes are staged BEHIND the first x blocks: both are cold fetches, and at
+    // small batches (one or two chains per workgroup) the prologue is a large part of the kernel
+#pragma unroll
+    for (int u = tid; u < (H / 16) * 64; u += S3_THREADS) {
+        const int col = u & 63, yg = u >> 6;                 // col = part*32 + f, yg = 2 kb + h
+        const float* src = ey_t + ((size_t)t * H + yg * 8) * 64 + col;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * 64];
+        u32x4 p0, p1, p2;
+        split3(v, p0, p1, p2);
+        const int kb = yg >> 1, hh = yg & 1, part = col >> 5, f = col & 31;
+        u32x4* dst = eyp + (((kb * 2 + part) * 3) * 2 + hh) * 32 + f;
+        dst[0] = p0; dst[64] = p1; dst[128] = p2;
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < n_it; ++it) {
         const float* xnext = frame_ptr(min(it + 1, n_it - 1));
@@ -268,6 +348,53 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
             const int b = S3_CHAIN(it), c = lane >> 5, f = lane & 31;
             if (f < F) vis[(((size_t)b * T + t) * F + f) * 2 + c] = s;
             else if (f == F && c == 0) flux[(size_t)b * T + t] = s;
+            if (FUSED) {
+                // closure phases of the frame, one triangle per lane (blackhole.py:341-363, 472-474)
+                const int f0 = cpk & 31, f1 = (cpk >> 5) & 31, f2 = (cpk >> 10) & 31;
+                const float2 v0 = make_float2(__shfl(s, f0), __shfl(s, 32 + f0));
+                const float2 v1 = make_float2(__shfl(s, f1), __shfl(s, 32 + f1));
+                const float2 v2 = make_float2(__shfl(s, f2), __shfl(s, 32 + f2));
+                const float fl = __shfl(s, F);
+                float acc = 0.f;
+                if (ck >= 0) {
+                    const float2 p = cmul(cmul(cdir(v0, (cpk >> 15) & 1), cdir(v1, (cpk >> 16) & 1)),
+                                          cdir(v2, (cpk >> 17) & 1));
+                    const float d = cy - atan2f(p.y, p.x);
+                    acc = one_minus_cos(d, fz.cphase_form) * cis;
+                    fz.dcp[(size_t)b * fz.Kcp + ck] = -sinf(d) * cis;
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    const float r = (fl - yfl) * 0.5f;                     // blackhole.py:490-491
+                    float* Sp = fz.S + ((size_t)b * T + t) * 4;
+                    Sp[0] = acc;
+                    Sp[2] = r * r;
+                }
+            }
+        }
+        if (FUSED && strip == 1) {
+            // wave 1 sums the strips again for itself and takes the log closure amplitudes, one
+            // quadrangle per lane (blackhole.py:365-391, 482-483)
+            const float* sp = sred + (it & 1) * NPART * 64 + lane;
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < NPART; ++p) s += sp[p * 64];
+            const int b = S3_CHAIN(it);
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fj = (cpk >> (5 * j)) & 31;
+                a[j] = cabs(make_float2(__shfl(s, fj), __shfl(s, 32 + fj)));
+            }
+            float acc = 0.f;
+            if (ck >= 0) {
+                const float l = logf(a[0]) + logf(a[1]) - logf(a[2]) - logf(a[3]);
+                const float r = (l - cy) * cis;
+                acc = r * r;
+                fz.dca[(size_t)b * fz.Kca + ck] = 2.0f * r * cis;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) fz.S[((size_t)b * T + t) * 4 + 1] = acc;
         }
         xcur = xnext;
     }
@@ -279,20 +406,32 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_fwd_s3(
 template <int H, int W>
 static void launch_fwd_s3(const float* ey_t, const float* ex_ri, int T, int F, const float* x, int B,
                           float scale, float shift, float clip_min, float* vis, float* flux,
-                          hipStream_t st) {
+                          const S3FusedFwd* fz, hipStream_t st) {
     constexpr int R = (H / 32 < S3_RING) ? H / 32 : S3_RING;
     int cpw, gx;
     s3_grid(B, T, &cpw, &gx);
     const size_t lds = (size_t)(H / 32) * 384 * 16 + (size_t)2 * 2 * (W / 32) * 64 * 4;
-    if (clip_min == -INFINITY) {
-        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, false>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false>), dim3(gx * T), dim3(S3_THREADS), lds, st,
-                           ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
+    if (fz) {                                                // the fused step never clips
+        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, false, true>, lds);
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false, true>), dim3(gx * T), dim3(S3_THREADS), lds, st,
+                           ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min, *fz);
+    } else if (clip_min == -INFINITY) {
+        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, false, false>, lds);
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, false, false>), dim3(gx * T), dim3(S3_THREADS), lds, st,
+                           ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min, S3FusedFwd{});
     } else {
-        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, true>, lds);
-        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, true>), dim3(gx * T), dim3(S3_THREADS), lds, st,
-                           ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min);
+        step_allow_lds((const void*)k_dft_fwd_s3<H, W, R, true, false>, lds);
+        hipLaunchKernelGGL((k_dft_fwd_s3<H, W, R, true, false>), dim3(gx * T), dim3(S3_THREADS), lds, st,
+                           ey_t, ex_ri, x, vis, flux, T, F, B, cpw, scale, shift, clip_min, S3FusedFwd{});
     }
+}
+
+static void dispatch_fwd_s3(const float* ey_t, const float* ex_ri, int T, int F, int H, const float* x,
+                            int B, float scale, float shift, float clip_min, float* vis, float* flux,
+                            const S3FusedFwd* fz, hipStream_t st) {
+    if (H == 256) launch_fwd_s3<256, 256>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis, flux, fz, st);
+    else if (H == 128) launch_fwd_s3<128, 128>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis, flux, fz, st);
+    else launch_fwd_s3<64, 64>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis, flux, fz, st);
 }
 
 extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int F, int H, int W,
@@ -302,11 +441,7 @@ extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_fwd_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_fwd_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
-    hipStream_t st = (hipStream_t)stream;
-    if (H == 256) launch_fwd_s3<256, 256>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
-    else if (H == 128) launch_fwd_s3<128, 128>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
-
-    else launch_fwd_s3<64, 64>(ey_t, ex_ri, T, F, x, B, scale, shift, clip_min, vis_c64, flux, st);
+    dispatch_fwd_s3(ey_t, ex_ri, T, F, H, x, B, scale, shift, clip_min, vis_c64, flux, nullptr, (hipStream_t)stream);
     STEP_CHECK_LAUNCH("bh_dft_fwd_sep3");
     return STEP_OK;
 }
@@ -316,17 +451,18 @@ extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int
 // [(((part*2 + kb)*3 + plane)*2 + h)][H/2 rows y]; part 0 = Re ey (with the flux row f = F,
 // ey = 1), part 1 = Im ey; kb = block of 16 baselines.  B operand per chain in registers:
 // wR[f][x] = Re(conj(ex) g) = exR gR + exI gI,  wI[f][x] = Im(conj(ex) g) = exR gI - exI gR.
-template <int H, int W>
+template <int H, int W, bool FUSED>
 __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
     const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, int B, int cpw,
-    float out_scale, const float* __restrict__ sum_in, int sum_n, float* __restrict__ sum_out) {
+    float out_scale, const float* __restrict__ sum_in, int sum_n, float* __restrict__ sum_out,
+    S3FusedAdj fz) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
     constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
     // optional rider: sum_out = sum(sum_in[0 .. sum_n)) in a fixed order (the scalar loss that
     // gradient(return_loss=True) returns, daps.py:100) -- saves a reduction launch per step
-    if (sum_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    if (!FUSED && sum_out && blockIdx.x == 0 && threadIdx.x < 64) {
         float sacc = 0.f;
         for (int i = threadIdx.x; i < sum_n; i += 64) sacc += sum_in[i];
         sacc = wave_sum(sacc);
@@ -335,6 +471,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
     u32x4* eyp = lds4;
     float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
+    float* fac = gl + S3_GCH * S3_GROW;                      // FUSED: [S3_GCH][2] backward factors, then [8]
     const int t = blockIdx.x % T, grp = blockIdx.x / T;      // s3_grid: why a 1-D grid
     const int tid = threadIdx.x, lane = tid & 63, strip = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -350,6 +487,21 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         const int f = (q >> 3) * 16 + 8 * h + (q & 7);
         exr[q] = ex_ri[(((size_t)t * 2 + 0) * 32 + f) * W + xcol];
         exi[q] = ex_ri[(((size_t)t * 2 + 1) * 32 + f) * W + xcol];
+    }
+    // FUSED: the incidence lists of this frame's baselines, relative to the frame, into LDS:
+    // lcsr = cp_ptr[F + 1] (at 0) | ca_ptr[F + 1] (at 34) | cp_ent[<= 192] (at 68) | ca_ent[<= 256]
+    int* lcsr = (int*)(fac + 2 * S3_GCH + 8);
+    if (FUSED) {
+        const int m0 = t * F;
+        const int bcp = fz.w_cp > 0.f ? fz.cp_ptr[m0] : 0, bca = fz.w_camp > 0.f ? fz.ca_ptr[m0] : 0;
+        const int ncp = fz.w_cp > 0.f ? fz.cp_ptr[m0 + F] - bcp : 0;
+        const int nca = fz.w_camp > 0.f ? fz.ca_ptr[m0 + F] - bca : 0;
+        if (tid <= F) {
+            lcsr[tid] = fz.w_cp > 0.f ? fz.cp_ptr[m0 + tid] - bcp : 0;
+            lcsr[34 + tid] = fz.w_camp > 0.f ? fz.ca_ptr[m0 + tid] - bca : 0;
+        }
+        if (tid < ncp) lcsr[68 + tid] = fz.cp_ent[bcp + tid];           // <= 192 and <= 256 entries:
+        if (tid < nca) lcsr[68 + 192 + tid] = fz.ca_ent[bca + tid];     // bh_build_frame_closures
     }
 #pragma unroll
     for (int u = tid; u < 8 * HH; u += S3_THREADS) {
@@ -374,14 +526,84 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     for (int c0 = 0; c0 < n_it; c0 += S3_GCH) {
         const int nch = min(S3_GCH, n_it - c0);
         __syncthreads();                                     // planes staged / gl free again
-        for (int u = tid; u < nch * 33; u += S3_THREADS) {
-            const int c = u / 33, e = u - c * 33;
-            const size_t bt = (size_t)S3_CHAIN(c0 + c) * T + t;
-            if (e < 32) {
-                const float2 g_ = ((const float2*)gvis)[bt * F + min(e, F - 1)];
-                *(float2*)(gl + c * S3_GROW + 2 * e) = g_;
-            } else {
-                gl[c * S3_GROW + 64] = gflux[bt];
+        if (FUSED) {
+            // per chain: chi^2 sums over the frames -> the two backward factors; a wave takes chains
+            // strip, strip + 8, ... two at a time (both loads in flight together)
+            for (int c = strip; c < nch; c += 2 * (S3_THREADS / 64)) {
+                const int c2 = c + S3_THREADS / 64 < nch ? c + S3_THREADS / 64 : c;
+                const int b1 = S3_CHAIN(c0 + c), b2 = S3_CHAIN(c0 + c2);
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+                for (int tt = lane; tt < T; tt += 64) {
+                    const float4 s4 = ((const float4*)fz.S)[(size_t)b1 * T + tt];
+                    const float4 r4 = ((const float4*)fz.S)[(size_t)b2 * T + tt];
+                    a0 += s4.x; a1 += s4.y; a2 += s4.z;
+                    e0 += r4.x; e1 += r4.y; e2 += r4.z;
+                }
+                a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+                e0 = wave_sum(e0); e1 = wave_sum(e1); e2 = wave_sum(e2);
+                float f_cp, f_ca, L, c_cp, c_ca, c_fl;
+                s3_chain_factors(fz, T, a0, a1, a2, f_cp, f_ca, L, c_cp, c_ca, c_fl);
+                if (lane == 0) { fac[2 * c] = f_cp; fac[2 * c + 1] = f_ca; }
+                s3_chain_factors(fz, T, e0, e1, e2, f_cp, f_ca, L, c_cp, c_ca, c_fl);
+                if (lane == 0) { fac[2 * c2] = f_cp; fac[2 * c2 + 1] = f_ca; }
+            }
+            __syncthreads();
+            // g_vis of this frame's baselines: gather of the derivative terms through the incidence
+            // lists, in the order of k_closure_loss.  The lists come
+            // from LDS and the terms are fetched eight at a time, triangles and quadrangles
+            // together: one round trip to memory instead of two per list entry.
+            const int M = T * F;
+            for (int u = tid; u < nch * 33; u += S3_THREADS) {
+                const int c = u / 33, e = u - c * 33;
+                const int b = S3_CHAIN(c0 + c);
+                if (e < 32) {
+                    const int fe = min(e, F - 1);
+                    const float2 v = fz.vis[(size_t)b * M + t * F + fe];
+                    const float* dP = fz.dcp + (size_t)b * fz.Kcp;
+                    const float* dA = fz.dca + (size_t)b * fz.Kca;
+                    const int p0 = lcsr[fe], p1 = lcsr[fe + 1], q0 = lcsr[34 + fe], q1 = lcsr[34 + fe + 1];
+                    float gp = 0.f, ga = 0.f;
+                    for (int o = 0; p0 + o < p1 || q0 + o < q1; o += 8) {
+                        int en[8], eq[8];
+                        float dv[8], dq[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const bool okp = p0 + o + j < p1, okq = q0 + o + j < q1;
+                            en[j] = okp ? lcsr[68 + p0 + o + j] : -1;
+                            eq[j] = okq ? lcsr[68 + 192 + q0 + o + j] : -1;
+                            dv[j] = okp ? dP[en[j] >> 3] : 0.f;
+                            dq[j] = okq ? dA[eq[j] >> 3] : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (en[j] >= 0) gp += (en[j] & 1) ? -dv[j] : dv[j];       // conj leg: -arg
+                            if (eq[j] >= 0) ga += (((eq[j] >> 1) & 3) < 2) ? dq[j] : -dq[j];
+                        }
+                    }
+                    gp *= fac[2 * c];
+                    ga *= fac[2 * c + 1];
+                    const float n2 = v.x * v.x + v.y * v.y;
+                    float2 g_ = make_float2(0.f, 0.f);
+                    if (fz.w_cp > 0.f || fz.w_camp > 0.f)
+                        g_ = make_float2((ga * v.x - gp * v.y) / n2, (ga * v.y + gp * v.x) / n2);
+                    *(float2*)(gl + c * S3_GROW + 2 * e) = g_;
+                } else {
+                    float g_ = 0.f;
+                    if (fz.w_flux > 0.f)
+                        g_ = fz.w_flux * (fz.flux[(size_t)b * T + t] - fz.y_fl[t]) * 0.5f / T;
+                    gl[c * S3_GROW + 64] = g_;
+                }
+            }
+        } else {
+            for (int u = tid; u < nch * 33; u += S3_THREADS) {
+                const int c = u / 33, e = u - c * 33;
+                const size_t bt = (size_t)S3_CHAIN(c0 + c) * T + t;
+                if (e < 32) {
+                    const float2 g_ = ((const float2*)gvis)[bt * F + min(e, F - 1)];
+                    *(float2*)(gl + c * S3_GROW + 2 * e) = g_;
+                } else {
+                    gl[c * S3_GROW + 64] = gflux[bt];
+                }
             }
         }
         __syncthreads();
@@ -443,19 +665,71 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
             }
         }
     }
+    if (FUSED && blockIdx.x == 0) {
+        // workgroup 0, once its tiles are stored (off the path of everybody's first store): every
+        // chain's loss (and raw chi^2) and their total, in a fixed order:
+        // wave w takes chains w, w + 8, ...; the eight partial totals are added in wave order
+        float wtot = 0.f;
+        for (int b = strip; b < B; b += S3_THREADS / 64) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int tt = lane; tt < T; tt += 64) {
+                const float4 s4 = ((const float4*)fz.S)[(size_t)b * T + tt];
+                a0 += s4.x; a1 += s4.y; a2 += s4.z;
+            }
+            a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+            float f_cp, f_ca, L, c_cp, c_ca, c_fl;
+            s3_chain_factors(fz, T, a0, a1, a2, f_cp, f_ca, L, c_cp, c_ca, c_fl);
+            wtot += L;
+            if (lane == 0) {
+                fz.loss[b] = L;
+                if (fz.chi2) {
+                    float* c = fz.chi2 + (size_t)b * 5;
+                    c[0] = 0.f; c[1] = 0.f; c[2] = c_cp; c[3] = c_ca; c[4] = c_fl;
+                }
+            }
+        }
+        if (fz.total) {
+            if (lane == 0) fac[2 * S3_GCH + strip] = wtot;
+            __syncthreads();
+            if (tid == 0) {
+                float tsum = 0.f;
+#pragma unroll
+                for (int w = 0; w < S3_THREADS / 64; ++w) tsum += fac[2 * S3_GCH + w];
+                *fz.total = tsum;
+            }
+        }
+    }
 #undef S3_STG
 }
 
 template <int H, int W>
 static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, const float* gvis,
                           const float* gflux, const float* chain_scale, int B, float out_scale,
-                          float* grad, const float* sum_in, int sum_n, float* sum_out, hipStream_t st) {
+                          float* grad, const float* sum_in, int sum_n, float* sum_out,
+                          const S3FusedAdj* fz, hipStream_t st) {
     int cpw, gx;
     s3_grid(B, T, &cpw, &gx);
-    const size_t lds = (size_t)24 * (H / 2) * 16 + (size_t)S3_GCH * S3_GROW * 4;
-    step_allow_lds((const void*)k_dft_adj_s3<H, W>, lds);
-    hipLaunchKernelGGL((k_dft_adj_s3<H, W>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
-                       gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out);
+    const size_t lds = (size_t)24 * (H / 2) * 16 + (size_t)S3_GCH * S3_GROW * 4 + (2 * S3_GCH + 8) * 4 +
+                       (68 + 192 + 256) * 4;
+    if (fz) {
+        step_allow_lds((const void*)k_dft_adj_s3<H, W, true>, lds);
+        hipLaunchKernelGGL((k_dft_adj_s3<H, W, true>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
+                           gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out, *fz);
+    } else {
+        step_allow_lds((const void*)k_dft_adj_s3<H, W, false>, lds);
+        hipLaunchKernelGGL((k_dft_adj_s3<H, W, false>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
+                           gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,
+                           S3FusedAdj{});
+    }
+}
+
+static void dispatch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, int H, const float* gvis,
+                            const float* gflux, const float* chain_scale, int B, float out_scale,
+                            float* grad, const float* sum_in, int sum_n, float* sum_out,
+                            const S3FusedAdj* fz, hipStream_t st) {
+    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
+    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
+    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
 }
 
 extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
@@ -467,11 +741,45 @@ extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, in
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_adj_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
-    hipStream_t st = (hipStream_t)stream;
-    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
-    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
-
-    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, st);
+    dispatch_adj_s3(ey_ri, ex_ri, T, F, H, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n,
+                    sum_out, nullptr, (hipStream_t)stream);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3");
+    return STEP_OK;
+}
+
+// ------------------------------------------------------------------------------- fused step
+extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri, int T, int F,
+                                 int H, int W, const float* x, int B, const bh_tables_t* tab,
+                                 const int32_t* frame_tab, const bh_meas_t* y, const bh_weights_t* w,
+                                 const bh_step_ws_t* ws, const float* chain_scale, float out_scale,
+                                 float* loss, float* chi2, float* loss_total, float* grad, void* stream) {
+    STEP_REQUIRE(ey_t && ey_ri && ex_ri && x && tab && frame_tab && y && w && ws && loss && grad,
+                 "bh_loss_grad_sep3: null pointer");
+    STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
+                 "bh_loss_grad_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
+    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_loss_grad_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
+    STEP_REQUIRE(tab->n_vis == T * F && tab->T == T, "bh_loss_grad_sep3: tables are for n_vis=%d T=%d", tab->n_vis, tab->T);
+    STEP_REQUIRE(y->batch == 1, "bh_loss_grad_sep3: one measurement for all chains (batch %d); use the three-kernel path", y->batch);
+    STEP_REQUIRE(!(w->w_vis > 0) && !(w->w_amp > 0), "bh_loss_grad_sep3: visibility / amplitude terms need the three-kernel path");
+    STEP_REQUIRE(w->cphase_form == 0 || w->cphase_form == 1, "bh_loss_grad_sep3: cphase_form %d", w->cphase_form);
+    STEP_REQUIRE(!(w->w_cp > 0) || (tab->n_tri > 0 && y->cphase && y->sigma_cphase && tab->cp_ptr && tab->cp_ent),
+                 "bh_loss_grad_sep3: cphase data / tables missing");
+    STEP_REQUIRE(!(w->w_camp > 0) || (tab->n_quad > 0 && y->logcamp && y->sigma_logcamp && tab->ca_ptr && tab->ca_ent),
+                 "bh_loss_grad_sep3: logcamp data / tables missing");
+    STEP_REQUIRE(y->flux, "bh_loss_grad_sep3: flux data missing");
+    STEP_REQUIRE(ws->vis_c64 && ws->flux && ws->dcp && ws->dca && ws->S, "bh_loss_grad_sep3: null workspace");
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_cp = w->w_cp > 0, use_ca = w->w_camp > 0;
+    S3FusedFwd ff{frame_tab, use_cp ? y->cphase : nullptr, use_cp ? y->sigma_cphase : nullptr,
+                  use_ca ? y->logcamp : nullptr, use_ca ? y->sigma_logcamp : nullptr, y->flux,
+                  ws->dcp, ws->dca, ws->S, tab->n_tri, tab->n_quad, w->cphase_form};
+    dispatch_fwd_s3(ey_t, ex_ri, T, F, H, x, B, 0.5f, 0.5f, -INFINITY, ws->vis_c64, ws->flux, &ff, st);
+    STEP_CHECK_LAUNCH("bh_loss_grad_sep3 (forward)");
+    S3FusedAdj fa{(const float2*)ws->vis_c64, ws->flux, ws->S, ws->dcp, ws->dca, tab->cp_ptr, tab->cp_ent,
+                  tab->ca_ptr, tab->ca_ent, y->flux, w->w_cp, w->w_camp, w->w_flux, w->normalize,
+                  tab->n_tri, tab->n_quad, loss, chi2, loss_total};
+    dispatch_adj_s3(ey_ri, ex_ri, T, F, H, nullptr, nullptr, chain_scale, B, out_scale, grad, nullptr, 0,
+                    nullptr, &fa, st);
+    STEP_CHECK_LAUNCH("bh_loss_grad_sep3 (adjoint)");
     return STEP_OK;
 }

@@ -138,6 +138,46 @@ extern "C" int bh_build_incidence(const int64_t* cp_index, const int64_t* cp_con
     return STEP_OK;
 }
 
+// Per-frame closure lists for the fused step (bh_loss_grad_sep3): slot j of frame t holds one
+// triangle / quadrangle whose baselines all lie in [t F, (t + 1) F), with local indices.
+extern "C" int bh_build_frame_closures(const int64_t* cp_index, const int64_t* cp_conj, int64_t n_tri,
+                                       const int64_t* camp_index, int64_t n_quad, int T, int F,
+                                       int32_t* frame_tab) {
+    REQ(T > 0 && F > 0 && F <= 31 && n_tri >= 0 && n_quad >= 0 && frame_tab, "bh_build_frame_closures: bad arguments");
+    REQ(n_tri == 0 || (cp_index && cp_conj), "bh_build_frame_closures: null triangle tables");
+    REQ(n_quad == 0 || camp_index, "bh_build_frame_closures: null quadrangle tables");
+    for (int64_t i = 0; i < (int64_t)T * 2 * 64; ++i) { frame_tab[2 * i] = -1; frame_tab[2 * i + 1] = 0; }
+    std::vector<int> fill(2 * (size_t)T, 0);
+    auto place = [&](const int64_t* idx, const int64_t* conj, int legs, int64_t k, int kind) -> int {
+        const int64_t t = idx[0] / F;
+        REQ(idx[0] >= 0 && t < T, "bh_build_frame_closures: baseline index %lld out of range", (long long)idx[0]);
+        int32_t packed = 0;
+        for (int j = 0; j < legs; ++j) {
+            REQ(idx[j] >= t * F && idx[j] < (t + 1) * F,
+                "bh_build_frame_closures: %s %lld spans frames (baselines %lld and %lld)",
+                kind ? "quadrangle" : "triangle", (long long)k, (long long)idx[0], (long long)idx[j]);
+            packed |= (int32_t)(idx[j] - t * F) << (5 * j);
+            if (conj) {
+                REQ(conj[j] == 0 || conj[j] == 1, "bh_build_frame_closures: conjugate flag %lld", (long long)conj[j]);
+                packed |= (int32_t)conj[j] << (15 + j);
+            }
+        }
+        int& n = fill[2 * t + kind];
+        REQ(n < 64, "bh_build_frame_closures: frame %lld has more than 64 %s", (long long)t,
+            kind ? "quadrangles" : "triangles");
+        int32_t* e = frame_tab + ((t * 2 + kind) * 64 + n) * 2;
+        e[0] = (int32_t)k;
+        e[1] = packed;
+        ++n;
+        return STEP_OK;
+    };
+    for (int64_t k = 0; k < n_tri; ++k)
+        if (int rc = place(cp_index + 3 * k, cp_conj + 3 * k, 3, k, 0)) return rc;
+    for (int64_t k = 0; k < n_quad; ++k)
+        if (int rc = place(camp_index + 4 * k, nullptr, 4, k, 1)) return rc;
+    return STEP_OK;
+}
+
 // ------------------------------------------------------------------ MRI mask
 // numpy's legacy global generator, as used by dynamic_mri.py:28,33:
 // np.random.seed(42) = MT19937 init_genrand(42); np.random.shuffle(a) on a 1-D array =

@@ -171,13 +171,23 @@ def _f32(t, device):
 
 
 class _LossFn(torch.autograd.Function):
-    """loss[b] with the fused adjoint as its backward (Appendix B of SURVEY.md)."""
+    """loss[b] with the fused adjoint as its backward (Appendix B of SURVEY.md).
+
+    ``unit_upstream``: the caller promises that the gradient arriving at the loss is exactly one
+    per chain (the loss is only summed: LatentWrapper.gradient).  The forward then runs the whole
+    fused step and the backward hands the stored gradient on; otherwise the backward is the adjoint
+    kernel scaled per chain by the upstream gradient."""
 
     @staticmethod
-    def forward(ctx, x, op, y):
+    def forward(ctx, x, op, y, unit_upstream):
         need = ctx.needs_input_grad[0]
-        loss, gvis, gflux = op._loss_forward(x.detach(), y, need)
         ctx.op, ctx.shape, ctx.dtype = op, x.shape, x.dtype
+        ctx.whole = bool(need and unit_upstream and op._fused_ok(y, x.shape[0]))
+        if ctx.whole:
+            loss, _, grad = op._fused_step(x.detach(), y, want_total=False)
+            ctx.save_for_backward(grad)
+            return loss
+        loss, gvis, gflux = op._loss_forward(x.detach(), y, need)
         if need:
             ctx.save_for_backward(gvis, gflux)
         return loss
@@ -185,9 +195,12 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
+        if ctx.whole:
+            (grad,) = ctx.saved_tensors
+            return grad.view(ctx.shape).to(ctx.dtype), None, None, None
         gvis, gflux = ctx.saved_tensors
         g = ctx.op._adjoint(gvis, gflux, _f32(grad_loss, gvis.device), 0.5)
-        return g.view(ctx.shape).to(ctx.dtype), None, None
+        return g.view(ctx.shape).to(ctx.dtype), None, None, None
 
 
 class _VisFn(torch.autograd.Function):
@@ -364,6 +377,14 @@ class BlackHoleImagingTorch(Operator):
                                      tt["camp_index"].data_ptr(), tt["cp_ptr"].data_ptr(),
                                      tt["cp_ent"].data_ptr(), tt["ca_ptr"].data_ptr(),
                                      tt["ca_ent"].data_ptr())
+        # per-frame closure lists of the fused two-launch step (None: some closure spans frames or
+        # a frame has more than 64 of a kind -> the three-kernel path)
+        ftab = np.zeros((T, 2, 64, 2), np.int32)
+        rc = _lib.lib().bh_build_frame_closures(_lib.ptr(cpi), _lib.ptr(cpc), cpi.shape[0], _lib.ptr(cai),
+                                                cai.shape[0], T, F, _lib.ptr(ftab)) if F <= 31 else -1
+        self._frame_tab = torch.from_numpy(ftab).to(dev) if rc == 0 else None
+        self._meas_cache = None
+        self.fused_step = True           # set False to force the three-kernel path (tests, A/B)
         self._weights = _lib.bh_weights_t(float(self.weight_vis), float(self.weight_amp),
                                           float(self.weight_cp), float(self.weight_camp),
                                           float(self.weight_flux), int(bool(loss_normalize)),
@@ -479,7 +500,20 @@ class BlackHoleImagingTorch(Operator):
         return grad, (total[0] if total is not None else sum_of.sum())
 
     def _meas(self, y):
-        """bh_meas_t for a BlackHoleObservation (+ the tensors that must outlive the launch)."""
+        """bh_meas_t for a BlackHoleObservation (+ the tensors that must outlive the launch).
+        The struct of the last measurement is kept: a sampler passes the same observation on every
+        step, and rebuilding nine tensors per step costs more host time than a small-batch step
+        takes on the GPU.  The cache is keyed on the object and on its tensors' storage."""
+        key = (id(y),) + tuple(None if getattr(y, k) is None else
+                               (getattr(y, k).data_ptr(), tuple(getattr(y, k).shape), getattr(y, k)._version)
+                               for k in BlackHoleObservation.FIELDS)
+        if self._meas_cache is not None and self._meas_cache[0] == key:
+            return self._meas_cache[1], self._meas_cache[2]
+        meas, keep = self._meas_build(y)
+        self._meas_cache = (key, meas, keep, y)
+        return meas, keep
+
+    def _meas_build(self, y):
         keep, ptrs = [], []
         for k in BlackHoleObservation.FIELDS:
             t = getattr(y, k)
@@ -514,6 +548,46 @@ class BlackHoleImagingTorch(Operator):
         _lib.check(rc, "bh_closure_loss")
         self.last_chi2 = chi2        # raw (vis, amp, cphase, logcamp, flux) per chain
         return loss, gvis, gflux
+
+    # The two-launch step saves the closure kernel and a launch gap (5-6 us per step) but its DFT
+    # kernels carry the closure work per chain (+0.2 us per chain and launch pair, rocprofv3,
+    # profiles/r02_*): it wins below ~32 chains per GPU, the three-kernel path above.
+    fused_max_batch = 31
+
+    def _fused_ok(self, y, B=None):
+        if B is not None and B > self.fused_max_batch:
+            return False
+        return (self.fused_step and self.path == "sep3" and self._frame_tab is not None
+                and self.weight_vis == 0 and self.weight_amp == 0
+                and y.flux is not None and y.flux.shape[0] == 1
+                and (self.weight_cp == 0 or (y.cphase is not None and y.cphase.shape[0] == 1))
+                and (self.weight_camp == 0 or (y.logcamp is not None and y.logcamp.shape[0] == 1)))
+
+    def _fused_step(self, x, y, want_total=True, chain_scale=None):
+        """The whole data step in two launches (bh_loss_grad_sep3): -> loss [B], total (0-d) or
+        None, grad [B, T, H*W] = d loss / d x."""
+        xv = self._video(x)
+        B, M, T, dev = xv.shape[0], self.T * self.F, self.T, self.device
+        Kcp, Kca = self.cphase_dim, self.logcamp_dim
+        # one allocation for every small buffer: S (16-byte aligned) first
+        sizes = (4 * B * T, 2 * B * M, B * T, B * Kcp, B * Kca, B, 5 * B, 4)
+        buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        S, vis, flux, dcp, dca, loss, chi2, total = torch.split(buf, sizes)
+        grad = torch.empty(B, T, self.H * self.W, device=dev, dtype=torch.float32)
+        ws = _lib.bh_step_ws_t(vis.data_ptr(), flux.data_ptr(), dcp.data_ptr(), dca.data_ptr(), S.data_ptr())
+        meas, keep = self._meas(y)
+        t0 = self._tick()
+        rc = _lib.lib().bh_loss_grad_sep3(
+            self._ey_t.data_ptr(), self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), T, self.F, self.H,
+            self.W, xv.data_ptr(), B, C.byref(self._tab), self._frame_tab.data_ptr(), C.byref(meas),
+            C.byref(self._weights), C.byref(ws), _lib.ptr(chain_scale), 0.5, loss.data_ptr(),
+            chi2.data_ptr(), total.data_ptr() if want_total else None, grad.data_ptr(),
+            _lib.stream_of(xv))
+        self._tock("fused_step", t0)
+        _lib.check(rc, "bh_loss_grad_sep3")
+        self.last_chi2 = chi2.view(B, 5)
+        self.last_vis = torch.view_as_complex(vis.view(B, M, 2))
+        return loss, (total[0] if want_total else None), grad
 
     def _observe(self, vis):
         vis = vis.detach().to(self.device, torch.complex64).contiguous()
@@ -643,12 +717,17 @@ class BlackHoleImagingTorch(Operator):
             "(blackhole.py:494-586); ehtim is not available to this build. Use op(x) for the "
             "noiseless observation or step_amd.forward_operator.blackhole.thermal_measure().")
 
-    def loss(self, x, y):
-        return _LossFn.apply(x, self, y)
+    def loss(self, x, y, unit_upstream=False):
+        return _LossFn.apply(x, self, y, unit_upstream)
 
     def gradient(self, x, y, return_loss=False):
         """Fused loss forward + adjoint (no autograd graph); same result as the base class's
-        autograd.grad of loss(x, y).sum()  (base.py:43-49)."""
+        autograd.grad of loss(x, y).sum()  (base.py:43-49).  Two launches on the default path
+        (closure stage inside the DFT kernels), three otherwise."""
+        if self._fused_ok(y, x.shape[0]):
+            loss, total, grad = self._fused_step(x, y, want_total=return_loss)
+            grad = grad.view(x.shape).to(x.dtype)
+            return (grad, total) if return_loss else grad
         loss, gvis, gflux = self._loss_forward(x, y, True)
         if return_loss:
             grad, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss)

@@ -34,10 +34,10 @@ class _ForwardFn(torch.autograd.Function):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, op, y):
+    def forward(ctx, x, op, y, unit_upstream):
         need = ctx.needs_input_grad[0]
         loss, grad = op._launch_loss_grad(_f32c(x, x.device), y, need, None)
-        ctx.dtype, ctx.op = x.dtype, op
+        ctx.dtype, ctx.unit = x.dtype, bool(unit_upstream)
         if need:
             ctx.save_for_backward(grad)
         return loss
@@ -46,10 +46,10 @@ class _LossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
         (grad,) = ctx.saved_tensors
-        if ctx.op._unit_upstream:          # LatentWrapper.gradient: the loss is only summed
-            return grad.to(ctx.dtype), None, None
+        if ctx.unit:                       # LatentWrapper.gradient: the loss is only summed
+            return grad.to(ctx.dtype), None, None, None
         g = grad * grad_loss.to(grad.dtype).view(-1, 1, 1, 1, 1)
-        return g.to(ctx.dtype), None, None
+        return g.to(ctx.dtype), None, None, None
 
 
 @register_operator('mri')
@@ -80,7 +80,6 @@ class DynamicMRI(Operator):
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
     kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined
-    _unit_upstream = False   # set by LatentWrapper.gradient around its autograd.grad call
 
     def _tables(self, device):
         key = str(device)
@@ -151,8 +150,10 @@ class DynamicMRI(Operator):
         # [B, T, C, H, W] -> masked k-space, same layout (dynamic_mri.py:42-48)
         return _ForwardFn.apply(x, self)
 
-    def loss(self, x, y):
-        return _LossFn.apply(x, self, y)
+    def loss(self, x, y, unit_upstream=False):
+        """``unit_upstream=True``: the caller only sums the loss (LatentWrapper.gradient), so the
+        backward hands on the gradient computed in the forward without a scaling pass."""
+        return _LossFn.apply(x, self, y, unit_upstream)
 
     def gradient(self, x, y, return_loss=False):
         loss, grad = self._launch_loss_grad(_f32c(x, x.device), y, True, None)
