@@ -299,6 +299,21 @@ int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, c
                 const float* eps, int64_t n, const mcmc_params_t* p, int32_t* nan_flag,
                 void* stream);
 
+/* mcmc_update with the noise drawn inside the kernel (algo 0 / 1): epsilon of daps.py:192 never
+ * exists in HBM.  Philox4x32-10, key = seeds[b] (the chain's own 64-bit seed, DEVICE int64
+ * [n / chain_len]), counter = (float4 index within the chain, step); normals by Box-Muller.  The
+ * noise of a chain depends only on (seed, step, element) -- not on the batch it runs in, the rank
+ * or the launch geometry -- which is what makes sharded runs reproducible per chain.  It is NOT
+ * torch's random stream: parity with the reference's draws is statistical (the reference's
+ * stream is replayed through mcmc_update with an explicit eps).
+ * step_dev (may be NULL): device int64 holding the step, read instead of `step` (graph replay).
+ * eps_out (may be NULL): receives the noise that was used.  chain_len % 4 == 0, 16-byte aligned
+ * buffers. */
+int mcmc_update_philox(float* x, float* velocity, const float* grad, const float* xt,
+                       const float* prior, int64_t n, const mcmc_params_t* p, const int64_t* seeds,
+                       int64_t chain_len, int64_t step, const int64_t* step_dev, float* eps_out,
+                       int32_t* nan_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ the reference's 8x down-factor) through LatentWrapper to show the autograd path.
 usage: python scripts/bench_sampler.py [--batch 64] [--steps 60] [--reps 5] [--latent]"""
 import argparse, sys, time
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from step_amd import eht_lite
 from step_amd.forward_operator import BlackHoleImagingTorch, LatentWrapper
 from step_amd.sampler import MCMCSampler
@@ -16,6 +16,7 @@ p.add_argument('--batch', type=int, default=64)
 p.add_argument('--steps', type=int, default=60)
 p.add_argument('--reps', type=int, default=5)
 p.add_argument('--latent', action='store_true')
+p.add_argument('--noise', default='torch', choices=['torch', 'philox'])
 a = p.parse_args()
 dev = torch.device('cuda:0')
 tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
@@ -38,7 +39,9 @@ class StandIn(torch.nn.Module):
 
 
 mc = MCMCSampler(num_steps=a.steps, lr=1.2e-5, tau=0.021, lr_min_ratio=0.015, prior_solver='gaussian',
-                 mc_algo='hmc', momentum=0.0)
+                 mc_algo='hmc', momentum=0.0, noise=a.noise)
+if a.noise == 'philox':
+    mc.set_chains(seeds=torch.arange(37, 37 + a.batch, dtype=torch.int64, device=dev))
 if a.latent:
     model = StandIn().to(dev)
     target, shape = LatentWrapper(op, model), (a.batch, 64, 1, 32, 32)
@@ -54,6 +57,6 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 assert torch.isfinite(out).all()
-print('%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
+print('noise=%s ' % a.noise + '%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
       % ('latent+stand-in decoder' if a.latent else 'pixel space', a.batch, a.steps, 1e3 * dt / a.steps,
          a.batch * a.steps / dt, 25 * dt * 60 / a.steps, 3600 * a.batch / (25 * dt * 60 / a.steps)))

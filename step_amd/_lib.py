@@ -84,6 +84,8 @@ SIGNATURES = {
                             c_p, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                    c_p, c_p]),
+    "mcmc_update_philox": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_i64,
+                                 c_i64, c_p, c_p, c_p, c_p]),
     "mcmc_update": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_p]),
 }
 

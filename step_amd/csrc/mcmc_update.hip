@@ -29,16 +29,51 @@ __device__ __forceinline__ float mcmc_elem(float xi, float g, float xti, float p
 
 #define MCMC_CHUNK_F4 16384      // float4 per array and chunk: 256 KB
 
+// ---- in-kernel noise: Philox4x32-10 (Salmon et al., SC'11), counter = (float4 index within the
+// chain, 0, step lo, step hi), key = the chain's 64-bit seed; four uniforms -> four normals by
+// Box-Muller.  A chain's noise depends only on (its seed, the step, the element): not on the
+// batch it is run in, the rank, or the launch geometry.  oracle/philox_oracle.py restates it.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// (u32 a, u32 b) -> two independent N(0,1): radius from a (uniform in (0,1]), angle from b
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1], 24 bits: exact
+    const float r = sqrtf(-2.0f * logf(u));
+    float sn, cs;
+    sincospif((float)(b >> 8) * (2.0f / 16777216.0f), &sn, &cs);          // angle 2 pi b / 2^32
+    n0 = r * cs;
+    n1 = r * sn;
+}
+
 // VEC = 4: every pointer 16-byte aligned and n % 4 == 0 (float4 accesses); VEC = 1 otherwise.
 // grad / prior / eps are read once and never again: non-temporal, so that x and the velocity
 // (read and written) keep the cache.
-template <int VEC>
+struct McmcNoise {               // PHILOX instantiation only
+    const int64_t* seeds;        // [n / chain_len] device
+    int64_t chain_f4;            // float4 per chain
+    int64_t step;                // used when step_dev is null
+    const int64_t* step_dev;     // device counter (graph replay): the step is read from here
+    float* eps_out;              // optional: the noise that was used (recording, tests)
+};
+
+template <int VEC, bool PHILOX>
 __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, float* __restrict__ vel,
                                                      const float* __restrict__ grad,
                                                      const float* __restrict__ xt,
                                                      const float* __restrict__ prior,
                                                      const float* __restrict__ eps, int64_t n,
-                                                     mcmc_params_t p, int32_t* __restrict__ nan_flag) {
+                                                     mcmc_params_t p, int32_t* __restrict__ nan_flag,
+                                                     McmcNoise nz) {
     bool bad = false;
     // momentum 0: the old velocity has weight zero in every later step, so it is neither read nor
     // stored (1 GB less traffic per step on a 64-chain black-hole state)
@@ -48,11 +83,23 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
     if (VEC == 4) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const int64_t n4 = n >> 2;
+        const uint64_t step = PHILOX ? (uint64_t)(nz.step_dev ? *nz.step_dev : nz.step) : 0;
         auto body = [&](int64_t i) {
             const f4 xi = ((const f4*)x)[i];
             const f4 g = __builtin_nontemporal_load((const f4*)grad + i);
             f4 e = {0.f, 0.f, 0.f, 0.f};
-            if (eps) e = __builtin_nontemporal_load((const f4*)eps + i);
+            if (PHILOX) {
+                const int64_t b = i / nz.chain_f4, j = i - b * nz.chain_f4;
+                const uint64_t seed = (uint64_t)nz.seeds[b];
+                uint32_t r[4];
+                philox4x32_10((uint32_t)j, (uint32_t)((uint64_t)j >> 32), (uint32_t)step, (uint32_t)(step >> 32),
+                              (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                float n0, n1, n2, n3;
+                box_muller(r[0], r[1], n0, n1);
+                box_muller(r[2], r[3], n2, n3);
+                e = f4{n0, n1, n2, n3};
+                if (nz.eps_out) ((f4*)nz.eps_out)[i] = e;
+            } else if (eps) e = __builtin_nontemporal_load((const f4*)eps + i);
             const f4 xti = ((const f4*)xt)[i];
             f4 pr = {0.f, 0.f, 0.f, 0.f}, vo = {0.f, 0.f, 0.f, 0.f}, xn, vn;
             if (prior) pr = __builtin_nontemporal_load((const f4*)prior + i);
@@ -94,6 +141,33 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
     if (nan_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
 }
 
+static int mcmc_blocks(int64_t n, bool vec) {
+    int64_t blocks = ((vec ? n / 4 : n) + 255) / 256;
+    return (int)(blocks > 4096 ? 4096 : blocks);
+}
+
+extern "C" int mcmc_update_philox(float* x, float* velocity, const float* grad, const float* xt,
+                                  const float* prior, int64_t n, const mcmc_params_t* p,
+                                  const int64_t* seeds, int64_t chain_len, int64_t step,
+                                  const int64_t* step_dev, float* eps_out, int32_t* nan_flag,
+                                  void* stream) {
+    STEP_REQUIRE(x && grad && xt && p && seeds, "mcmc_update_philox: null pointer");
+    STEP_REQUIRE(p->algo == 0 || p->algo == 1, "mcmc_update_philox: algo %d draws no noise", p->algo);
+    STEP_REQUIRE(p->algo != 1 || velocity, "mcmc_update_philox: hmc needs a velocity buffer");
+    STEP_REQUIRE(n > 0 && chain_len > 0 && n % chain_len == 0 && chain_len % 4 == 0,
+                 "mcmc_update_philox: n = %lld must be whole chains of chain_len = %lld (a multiple of 4)",
+                 (long long)n, (long long)chain_len);
+    STEP_REQUIRE(step >= 0, "mcmc_update_philox: negative step");
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
+                         (uintptr_t)prior | (uintptr_t)eps_out;
+    STEP_REQUIRE(al % 16 == 0, "mcmc_update_philox: buffers must be 16-byte aligned");
+    McmcNoise nz{seeds, chain_len / 4, step, step_dev, eps_out};
+    hipLaunchKernelGGL((k_mcmc_update<4, true>), dim3((unsigned)mcmc_blocks(n, true)), dim3(256), 0,
+                       (hipStream_t)stream, x, velocity, grad, xt, prior, nullptr, n, *p, nan_flag, nz);
+    STEP_CHECK_LAUNCH("mcmc_update_philox");
+    return STEP_OK;
+}
+
 extern "C" int mcmc_update(float* x, float* velocity, const float* grad, const float* xt,
                            const float* prior, const float* eps, int64_t n, const mcmc_params_t* p,
                            int32_t* nan_flag, void* stream) {
@@ -105,14 +179,13 @@ extern "C" int mcmc_update(float* x, float* velocity, const float* grad, const f
     const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
                          (uintptr_t)prior | (uintptr_t)eps;
     const bool vec = (n % 4 == 0) && (al % 16 == 0);
-    int64_t blocks = ((vec ? n / 4 : n) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = mcmc_blocks(n, vec);
     if (vec)
-        hipLaunchKernelGGL(k_mcmc_update<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag);
+        hipLaunchKernelGGL((k_mcmc_update<4, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag, McmcNoise{});
     else
-        hipLaunchKernelGGL(k_mcmc_update<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag);
+        hipLaunchKernelGGL((k_mcmc_update<1, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           x, velocity, grad, xt, prior, eps, n, *p, nan_flag, McmcNoise{});
     STEP_CHECK_LAUNCH("mcmc_update");
     return STEP_OK;
 }

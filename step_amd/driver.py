@@ -69,11 +69,16 @@ def gather_to_rank0(local, ids, n_items, group=None):
 
 
 def sample_posterior(sampler, model, operator, measurement, num_samples, seed=37, device=None,
-                     max_batch=None, evaluator=None, gt=None, group=None):
+                     max_batch=None, evaluator=None, gt=None, group=None, item_offset=0):
     """Draw `num_samples` posterior samples for ONE measurement, chains sharded over ranks and
     batched per rank.  Returns [num_samples, *video_shape] on rank 0 (None on other ranks).
 
-    sampler: LatentDAPS-like (get_start / sample); model: prior with get_latent_shape()."""
+    sampler: LatentDAPS-like (get_start / sample); model: prior with get_latent_shape().
+    Every random draw of chain c -- start noise, HMC velocity, Langevin noise, re-noising -- comes
+    from that chain's own generator / Philox seed (``seed + item_offset + c``) when the sampler has
+    ``set_chains`` (LatentDAPS does): a chain's result is then independent of the world size, of
+    `max_batch` and of which chains share its batch.  `item_offset` separates measurements
+    (test videos) that reuse one base seed."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     device = device or next(model.parameters()).device
@@ -82,17 +87,21 @@ def sample_posterior(sampler, model, operator, measurement, num_samples, seed=37
     step = max_batch or max(len(ids), 1)
     for i in range(0, len(ids), step):
         chunk = ids[i: i + step]
-        # per-chain start noise from per-chain generators; the in-loop noise of a batched call
-        # comes from the rank's default generator, seeded by the first chain of the chunk
-        z = torch.stack([torch.randn(*model.get_latent_shape(), device=device,
-                                     generator=chain_generator(seed, c, device)) for c in chunk])
-        if device.type == "cuda":
-            torch.cuda.manual_seed(int(seed) + 100003 * (chunk[0] + 1))
+        gens = [chain_generator(seed, item_offset + c, device) for c in chunk]
+        z = torch.stack([torch.randn(*model.get_latent_shape(), device=device, generator=g) for g in gens])
+        if hasattr(sampler, "set_chains"):
+            seeds = torch.tensor([int(seed) + item_offset + c for c in chunk], dtype=torch.int64, device=device)
+            sampler.set_chains(generators=gens, seeds=seeds)
         else:
-            torch.manual_seed(int(seed) + 100003 * (chunk[0] + 1))
+            # a sampler without per-chain randomness: its in-loop noise comes from the default
+            # generator, seeded per chunk (reproducible for a fixed sharding only)
+            (torch.cuda.manual_seed if device.type == "cuda" else torch.manual_seed)(
+                int(seed) + 100003 * (item_offset + chunk[0] + 1))
         z_start = z * sampler.annealing_scheduler.sigma_max
         kw = dict(gt=gt) if gt is not None else {}
         outs.append(sampler.sample(model, z_start, operator, measurement, evaluator=evaluator, **kw))
+        if hasattr(sampler, "set_chains"):
+            sampler.set_chains(None, None)
     if outs:
         local = torch.cat(outs, dim=0)
     else:                      # more ranks than chains: this rank contributes an empty shard

@@ -51,16 +51,43 @@ class Trajectory(nn.Module):
         return out
 
 
+def chain_randn_like(ref, generators=None):
+    """``torch.randn_like(ref)`` (the reference's draw, from the device's default generator) or,
+    with one generator per chain, chain b's slice from its own generator: the result for a chain
+    then does not depend on which other chains share the batch."""
+    if generators is None:
+        return torch.randn_like(ref)
+    if len(generators) != ref.shape[0]:
+        raise ValueError("%d chain generators for a batch of %d" % (len(generators), ref.shape[0]))
+    return torch.stack([torch.randn(ref.shape[1:], device=ref.device, dtype=ref.dtype, generator=g)
+                        for g in generators])
+
+
 class MCMCSampler(nn.Module):
     """Langevin / damped-HMC / Metropolis-Hastings inner loop.
 
     ``nan_check``: 'deferred' (default) keeps the NaN guard of daps.py:202-203 on the device and
     reads it once after the last step -- the returned tensor is identical (a NaN state stays NaN,
     the whole batch comes back as zeros) but no host synchronisation happens per step;
-    'step' reads it every step and returns early exactly like the reference."""
+    'step' reads it every step and returns early exactly like the reference.  Two differences of
+    'deferred' once a NaN HAS appeared: the loop runs on, so later
+    ``operator.gradient`` / ``model.score`` / noise draws still happen and the global RNG stream
+    seen by later annealing steps differs from the reference's; and with hmc at momentum 0
+    ``self.velocity`` keeps its initial draw (the kernel neither reads nor writes a velocity of
+    weight zero) where the reference leaves the last one.  Use 'step' for stream-exact replays.
+
+    ``nan_guard``: 'batch' (default, the reference: one NaN anywhere zeroes the whole batch) or
+    'chain' (only the chains that hold a NaN come back as zeros -- for batched / sharded drivers,
+    where unrelated chains share a batch; a behaviour change, off by default).
+
+    ``noise``: 'torch' (default) draws epsilon with torch.randn_like as the reference does
+    (daps.py:192), or chain by chain from ``set_chains(generators=...)``; 'philox' draws it inside
+    the update kernel from per-chain seeds (``set_chains(seeds=...)``): no noise tensor in HBM,
+    per-chain reproducible, statistical parity only."""
 
     def __init__(self, num_steps, lr, tau=0.01, lr_min_ratio=0.01, prior_solver='gaussian',
-                 prior_sigma_min=1e-2, mc_algo='langevin', momentum=0.9, nan_check='deferred'):
+                 prior_sigma_min=1e-2, mc_algo='langevin', momentum=0.9, nan_check='deferred',
+                 nan_guard='batch', noise='torch'):
         super().__init__()
         self.num_steps = num_steps
         self.lr = lr
@@ -72,6 +99,29 @@ class MCMCSampler(nn.Module):
         self.momentum = momentum
         assert nan_check in ('deferred', 'step')
         self.nan_check = nan_check
+        assert nan_guard in ('batch', 'chain')
+        self.nan_guard = nan_guard
+        assert noise in ('torch', 'philox')
+        self.noise = noise
+        self.chain_generators = None     # list of torch.Generator, one per chain, or None
+        self.chain_seeds = None          # int64 [B] on the device ('philox'), or None
+        self.noise_step = 0              # Philox counter: steps taken since set_chains
+
+    def set_chains(self, generators=None, seeds=None):
+        """Per-chain randomness for the next sample() calls: torch generators (start velocity,
+        'torch' noise) and/or 64-bit seeds ('philox' noise); resets the Philox step counter."""
+        self.chain_generators = list(generators) if generators is not None else None
+        self.chain_seeds = seeds
+        self.noise_step = 0
+
+    def _nan_result(self, x):
+        """The guard of daps.py:202-203 once the flag is up."""
+        if self.nan_guard == 'batch':
+            return torch.zeros_like(x)
+        bad = torch.isnan(x).flatten(1).any(dim=1)
+        x = x.clone()
+        x[bad] = 0
+        return x
 
     # ------------------------------------------------------------------ reference-shaped pieces
     def score_fn(self, x, x0hat, model, xt, operator, measurement, sigma):
@@ -101,7 +151,7 @@ class MCMCSampler(nn.Module):
 
     def mc_prepare(self, x0hat, xt, model, operator, measurement, sigma):
         if self.mc_algo == 'hmc':
-            self.velocity = torch.randn_like(x0hat)
+            self.velocity = chain_randn_like(x0hat, self.chain_generators)
 
     def mc_update(self, x, cur_score, lr, epsilon):
         """Unfused update (daps.py:135-144), kept for callers of the reference API."""
@@ -164,18 +214,36 @@ class MCMCSampler(nn.Module):
             self.velocity = self._kernel_tensor(self.velocity, x)
         params = self._params(lr, sigma)
         nan_flag = torch.zeros(1, device=x.device, dtype=torch.int32)
+        philox = self.noise == 'philox'
+        if philox:
+            seeds = self.chain_seeds
+            if seeds is None or seeds.numel() != x.shape[0]:
+                raise ValueError("noise='philox' needs set_chains(seeds=int64[%d])" % x.shape[0])
+            seeds = seeds.to(device=x.device, dtype=torch.int64).contiguous()
+            chain_len = x[0].numel()
         for _ in range(self.num_steps):
             grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
             prior = self.get_prior_score(x, x0hat, xt, model, sigma)
-            epsilon = torch.randn_like(x)
-            self._fused_update(x, self._kernel_tensor(grad, x), xt_k,
-                               self._kernel_tensor(prior, x), epsilon, params, nan_flag)
+            if philox:
+                epsilon = torch.empty_like(x) if record else None
+                vel = self.velocity if self.mc_algo == 'hmc' else None
+                rc = _lib.lib().mcmc_update_philox(
+                    x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), xt_k.data_ptr(),
+                    self._kernel_tensor(prior, x).data_ptr(), x.numel(), C.byref(params), seeds.data_ptr(),
+                    chain_len, self.noise_step, None, _lib.ptr(epsilon), nan_flag.data_ptr(),
+                    _lib.stream_of(x))
+                _lib.check(rc, "mcmc_update_philox")
+                self.noise_step += 1
+            else:
+                epsilon = chain_randn_like(x, self.chain_generators)
+                self._fused_update(x, self._kernel_tensor(grad, x), xt_k,
+                                   self._kernel_tensor(prior, x), epsilon, params, nan_flag)
             if self.nan_check == 'step' and nan_flag.item():
-                return torch.zeros_like(x)
+                return self._nan_result(x)
             if record:
                 self._record(x.clone(), epsilon, fitting_loss.sqrt())
         if self.nan_check == 'deferred' and nan_flag.item():
-            return torch.zeros_like(x)
+            return self._nan_result(x)
         return x.detach()
 
     def sample_MH(self, xt, model, x0hat, operator, measurement, sigma, ratio, record=False,
@@ -250,11 +318,19 @@ class LatentDAPS(nn.Module):
         self.mcmc_sampler = MCMCSampler(**mcmc_sampler_config)
         self.batch_consistency = batch_consistency
         self.latent_wrapper = latent_wrapper
+        self.chain_generators = None
+
+    def set_chains(self, generators=None, seeds=None):
+        """Per-chain randomness (step_amd.driver): every draw of the next sample() call -- start
+        and re-noising here, velocity and Langevin noise in the MCMC sampler -- comes from the
+        chain's own generator / seed, so a chain's result does not depend on the batch it is in."""
+        self.chain_generators = list(generators) if generators is not None else None
+        self.mcmc_sampler.set_chains(generators, seeds)
 
     def get_randn_like(self, ref):
         if self.batch_consistency:
-            return torch.randn_like(ref[:, 0]).unsqueeze(1).expand_as(ref)
-        return torch.randn_like(ref)
+            return chain_randn_like(ref[:, 0], self.chain_generators).unsqueeze(1).expand_as(ref)
+        return chain_randn_like(ref, self.chain_generators)
 
     def sample(self, model, z_start, operator, measurement, evaluator=None, record=False,
                verbose=False, **kwargs):
