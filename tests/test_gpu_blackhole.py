@@ -511,7 +511,7 @@ def test_measure_without_ehtim(dev, tmp_path):
     from step_amd import eht_lite
     from step_amd.forward_operator import BlackHoleImagingTorch, BlackHoleObservation
     from step_amd.forward_operator.blackhole import load_observation, save_observation
-    arr = os.path.join(os.path.dirname(__file__), "data", "array_8.txt")
+    arr = os.path.join(os.path.dirname(os.path.dirname(__file__)), "step_amd", "data", "array_8.txt")
     tab = eht_lite.eht_table(arr)
     # the elevation cuts leave fewer than 8 sites at some frames of this array on this date; use
     # the synthetic 8-site table for the gain test and the array table for the zero-spacing flux

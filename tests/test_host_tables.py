@@ -121,7 +121,7 @@ def test_minimal_sets_and_synthetic_table():
 
 
 def test_array_file_synthesis_shapes():
-    tab = eht_lite.eht_table(os.path.join(ROOT, "tests", "data", "array_8.txt"))
+    tab = eht_lite.eht_table(os.path.join(ROOT, "step_amd", "data", "array_8.txt"))
     T, F, _ = tab["uv"].shape
     assert T == 64                                              # 12.5 .. 14.3 h in 102 s steps
     n = round((1 + (1 + 8 * F) ** 0.5) / 2)
