@@ -261,6 +261,21 @@ int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int
                   const float* chain_scale, int variant, float* loss_part, float* loss,
                   float* loss_total, float* grad, void* stream);
 
+/* Multi-coil variants -- NO REFERENCE COUNTERPART (the reference operator is single-coil,
+ * dynamic_mri.py:42-48; BASELINE.json names the coil-sensitivity multiply): y_c = M * FFT2(fftshift(
+ * S_c * x)), c < C, with complex sensitivity maps sens [C][2][R][R] (Re, Im planes; static over
+ * frames and chains).  The coil loop runs inside the per-frame workgroup: x is owned by one
+ * workgroup for all coils and the gradient sum_c conj(S_c) A^H(2 r_c) accumulates in place.
+ * out / y: [B or By][T][C][2][R][R].  loss[b] = sum_c sum |A_c(x) - y_c|^2; loss_part: float[B*T].
+ * C = 1 with S = 1 + 0i gives mri_forward / mri_loss_grad(variant = 1) bit for bit. */
+int mri_forward_mc(const float* x, const float* sens, int C, int B, int T, int R,
+                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
+                   float* out, void* stream);
+int mri_loss_grad_mc(const float* x, const float* sens, int C, const float* y, int y_batch, int B,
+                     int T, int R, const int32_t* rows, const int32_t* nrows, int mask_frames,
+                     int max_rows, const float* chain_scale, float* loss_part, float* loss,
+                     float* loss_total, float* grad, void* stream);
+
 /* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
  * the reference.  Same arguments, kernels and results as mri_loss_grad(variant = 0); the

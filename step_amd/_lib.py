@@ -82,6 +82,9 @@ SIGNATURES = {
     "mri_adjoint": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p,
                             c_p, c_p, c_p]),
+    "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
+                               c_p, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                    c_p, c_p]),
     "mcmc_update_philox": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_i64,

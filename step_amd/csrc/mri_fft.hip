@@ -91,9 +91,11 @@ __device__ __forceinline__ void strip_fft_fwd(const MriLds& L, int strip, int g0
 
 // Inverse FFT along y for one strip: pass A gathers its inputs from the kept rows of the row
 // buffer (all other k_y rows are zero), pass B stores image rows straight from registers.
+template <bool MC = false>
 __device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0, int nk,
                                               float* __restrict__ dr, float* __restrict__ di,
-                                              bool accumulate) {
+                                              bool accumulate, const float* __restrict__ sr = nullptr,
+                                              const float* __restrict__ si = nullptr) {
     const int tid = threadIdx.x, col = tid & 31;
     if (tid < 12 * 32) {
         const int bb = tid >> 5;
@@ -117,8 +119,14 @@ __device__ __forceinline__ void strip_fft_inv(const MriLds& L, int strip, int g0
 #pragma unroll
         for (int d = 0; d < 12; ++d) {
             const int g = (c + 16 * d) * MRI_R + strip * MRI_SW + col;
-            if (accumulate) { dr[g] += v[d].x; di[g] += v[d].y; }
-            else { dr[g] = v[d].x; di[g] = v[d].y; }
+            float ox = v[d].x, oy = v[d].y;
+            if (MC) {                                 // conj(S_c) * v: the adjoint of the coil multiply
+                const float a = sr[g], b = si[g];
+                ox = v[d].x * a + v[d].y * b;
+                oy = v[d].y * a - v[d].x * b;
+            }
+            if (accumulate) { dr[g] += ox; di[g] += oy; }
+            else { dr[g] = ox; di[g] = oy; }
         }
     }
     __syncthreads();                                  // S is rewritten by the next strip's pass A
@@ -173,13 +181,21 @@ constexpr int MRI_NP = MRI_R * MRI_SW / MRI_THREADS;      // 12 elements of a st
 constexpr int MRI_YQ = 6;   // float4 loads per thread and strip for the masked-out rows (<= 192 rows)
 
 // pixels of strip `strip` owned by this thread: element i is row (tid >> 5) + 16 i, column tid & 31
+template <bool MC = false>
 __device__ __forceinline__ void load_strip(const float* __restrict__ xr, const float* __restrict__ xi,
-                                           int strip, cf32 (&pre)[MRI_NP]) {
+                                           int strip, cf32 (&pre)[MRI_NP],
+                                           const float* __restrict__ sr = nullptr,
+                                           const float* __restrict__ si = nullptr) {
     const int col = threadIdx.x & 31, row0 = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < MRI_NP; ++i) {
         const int g = (row0 + 16 * i) * MRI_R + strip * MRI_SW + col;
-        pre[i] = c_make(xr[g], xi[g]);
+        if (MC) {                                     // S_c * x (coil sensitivity, complex)
+            const float a = sr[g], b = si[g], p = xr[g], q = xi[g];
+            pre[i] = c_make(p * a - q * b, p * b + q * a);
+        } else {
+            pre[i] = c_make(xr[g], xi[g]);
+        }
     }
 }
 
@@ -189,10 +205,12 @@ __device__ __forceinline__ void load_strip(const float* __restrict__ xr, const f
 // so the residual is -y -- is summed along the way: each strip every thread loads its share of a
 // sixth of those rows as float4 before the strip's FFT and adds it up after, so the L2 latency
 // hides behind the transform.
+template <bool MC = false>
 __device__ __forceinline__ void forward_rows(const MriLds& L, const float* __restrict__ xr,
                                              const float* __restrict__ xi, int g0, int nk,
                                              cf32 (&pre)[MRI_NP], const float* __restrict__ y,
-                                             int n_un, float& acc) {
+                                             int n_un, float& acc, const float* __restrict__ sr = nullptr,
+                                             const float* __restrict__ si = nullptr) {
     const int tid = threadIdx.x;
     constexpr int NP = MRI_NP, NS = MRI_R / MRI_SW, Q = MRI_R / 4;   // Q float4 per row
     const int col = tid & 31, row0 = tid >> 5;             // element i: row = row0 + 16 i
@@ -201,7 +219,7 @@ __device__ __forceinline__ void forward_rows(const MriLds& L, const float* __res
         for (int i = 0; i < NP; ++i) L.S[(row0 + 16 * i) * MRI_SW + col] = pre[i];
         __syncthreads();
         // the next strip's pixels travel to registers while the current strip is transformed
-        if (strip + 1 < NS) load_strip(xr, xi, strip + 1, pre);
+        if (strip + 1 < NS) load_strip<MC>(xr, xi, strip + 1, pre, sr, si);
         float4 yq[MRI_YQ];
         const int q0 = strip * n_un / NS;
         const int total = y ? ((strip + 1) * n_un / NS - q0) * (2 * Q) : 0;   // both planes
@@ -295,11 +313,14 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward(
 
 // Steps 4-5 for kept rows [g0, g0+nk): Rk holds the (sign-folded) k-space rows; writes (g0 == 0)
 // or accumulates (later groups) the image-space result into the frame `dst` ([2][R][R]).
+template <bool MC = false>
 __device__ __forceinline__ void adjoint_rows(const MriLds& L, const int* __restrict__ rowlist,
-                                             int g0, int nk, float* __restrict__ dst) {
+                                             int g0, int nk, float* __restrict__ dst, bool accumulate,
+                                             const float* __restrict__ sr = nullptr,
+                                             const float* __restrict__ si = nullptr) {
     rows_fft_x<1>(L, nk);
     for (int strip = 0; strip < MRI_R / MRI_SW; ++strip)
-        strip_fft_inv(L, strip, g0, nk, dst, dst + MRI_R * MRI_R, g0 != 0);
+        strip_fft_inv<MC>(L, strip, g0, nk, dst, dst + MRI_R * MRI_R, accumulate, sr, si);
 }
 
 // ------------------------------------------------------------------------------- loss + gradient
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad(
             L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
         }
         __syncthreads();
-        if (grad) adjoint_rows(L, rowlist, g0, nk, grad + (size_t)frame * fsz);
+        if (grad) adjoint_rows(L, rowlist, g0, nk, grad + (size_t)frame * fsz, g0 != 0);
     }
     const float tot = block_sum(acc, L.red);
     if (tid == 0) loss_part[frame] = tot;
@@ -422,7 +443,116 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
                 c_make(s * gr[(size_t)ky * MRI_R + kx], s * gi[(size_t)ky * MRI_R + kx]);
         }
         __syncthreads();
-        adjoint_rows(L, rowlist, g0, nk, out + (size_t)frame * fsz);
+        adjoint_rows(L, rowlist, g0, nk, out + (size_t)frame * fsz, g0 != 0);
+    }
+}
+
+// ------------------------------------------------------------------------------- multi-coil
+// y_c = M * FFT2(fftshift(S_c * x)), c < C: the coil loop runs INSIDE the per-frame workgroup, so
+// x and the gradient belong to one workgroup from the first coil to the last (the gradient
+// accumulates in place: sum_c conj(S_c) * A^H(2 r_c)).  NO REFERENCE COUNTERPART -- the reference
+// operator is single-coil (dynamic_mri.py:42-48); C = 1 with S = 1 runs the very arithmetic of
+// k_mri_loss_grad / k_mri_forward (1 * x and x - 0 are exact), bit for bit.
+// sens: [C][2][R][R] (Re, Im planes, static over frames); y: [By][T][C][2][R][R].
+__global__ __launch_bounds__(MRI_THREADS) void k_mri_loss_grad_mc(
+    const float* __restrict__ x, const float* __restrict__ sens, int C, const float* __restrict__ y,
+    int y_batch, const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T,
+    int nkc, const float* __restrict__ chain_scale, float* __restrict__ loss_part,
+    float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MriLds L = carve(lds, nkc);
+    const int frame = blockIdx.x, b = frame / T, t = frame % T, tid = threadIdx.x;
+    const int mf = mask_frames == 1 ? 0 : t;
+    const int* rowlist = rows + (size_t)mf * MRI_R;
+    const int nk_total = nrows[mf];
+    const size_t fsz = (size_t)2 * MRI_R * MRI_R;
+    const float* xr = x + (size_t)frame * fsz;
+    const float* xi = xr + MRI_R * MRI_R;
+    const float cs2 = 2.f * (chain_scale ? chain_scale[b] : 1.f);
+    cf32 pre[MRI_NP];
+    load_strip<true>(xr, xi, 0, pre, sens, sens + MRI_R * MRI_R);    // in flight during the table set-up
+    load_tables(L, rowlist, nk_total);
+    float acc = 0.f;
+    if (nk_total == 0 && grad) {
+        float* gr = grad + (size_t)frame * fsz;
+        for (int e = tid; e < 2 * MRI_R * MRI_R; e += MRI_THREADS) gr[e] = 0.f;
+    }
+    for (int c = 0; c < C; ++c) {
+        const float* sr = sens + (size_t)c * fsz;
+        const float* si = sr + MRI_R * MRI_R;
+        const float* yr = y + (((size_t)(y_batch > 1 ? b : 0) * T + t) * C + c) * fsz;
+        const float* yi = yr + MRI_R * MRI_R;
+        if (nk_total == 0) {                               // nothing kept: the loss is sum |y_c|^2
+            for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS) {
+                const float a = yr[e], d = yi[e];
+                acc += a * a + d * d;
+            }
+        }
+        for (int g0 = 0; g0 < nk_total; g0 += nkc) {
+            const int nk = min(nkc, nk_total - g0);
+            if (c || g0) load_strip<true>(xr, xi, 0, pre, sr, si);
+            forward_rows<true>(L, xr, xi, g0, nk, pre, g0 == 0 ? yr : nullptr, MRI_R - nk_total, acc, sr, si);
+#pragma unroll 4
+            for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
+                const int j = e / MRI_R, kx = e - j * MRI_R;
+                const int ky = L.rowl[g0 + j];
+                const float sx = sgn(kx), sy = sgn(ky);
+                const float ya = yr[ky * MRI_R + kx], yb = yi[ky * MRI_R + kx];
+                const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
+                const float rr = sx * v.x - ya;
+                const float ri = sx * v.y - yb;
+                acc += rr * rr + ri * ri;
+                const float s = cs2 * sx * sy;
+                L.Rk[(size_t)j * MRI_RS + kx] = c_make(s * rr, s * ri);
+            }
+            __syncthreads();
+            // the stores of one coil are read back by the same threads for the next (each thread
+            // owns its pixels in strip_fft_inv), so no fence is needed between coils
+            if (grad) adjoint_rows<true>(L, rowlist, g0, nk, grad + (size_t)frame * fsz, c != 0 || g0 != 0, sr, si);
+        }
+    }
+    const float tot = block_sum(acc, L.red);
+    if (tid == 0) loss_part[frame] = tot;
+}
+
+// out[b][t][c] = M * FFT2(fftshift(S_c * x[b][t]))
+__global__ __launch_bounds__(MRI_THREADS) void k_mri_forward_mc(
+    const float* __restrict__ x, const float* __restrict__ sens, int C, const int* __restrict__ rows,
+    const int* __restrict__ nrows, int mask_frames, int T, int nkc, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MriLds L = carve(lds, nkc);
+    const int frame = blockIdx.x, t = frame % T, tid = threadIdx.x;
+    const int mf = mask_frames == 1 ? 0 : t;
+    const int* rowlist = rows + (size_t)mf * MRI_R;
+    const int nk_total = nrows[mf];
+    const size_t fsz = (size_t)2 * MRI_R * MRI_R;
+    const float* xr = x + (size_t)frame * fsz;
+    const float* xi = xr + MRI_R * MRI_R;
+    cf32 pre[MRI_NP];
+    load_strip<true>(xr, xi, 0, pre, sens, sens + MRI_R * MRI_R);
+    load_tables(L, rowlist, nk_total);
+    float unused = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* sr = sens + (size_t)c * fsz;
+        const float* si = sr + MRI_R * MRI_R;
+        float* outr = out + ((size_t)frame * C + c) * fsz;
+        float* outi = outr + MRI_R * MRI_R;
+        for (int e = tid; e < MRI_R * MRI_R; e += MRI_THREADS)
+            if (L.rowpos[e / MRI_R] < 0) { outr[e] = 0.f; outi[e] = 0.f; }
+        for (int g0 = 0; g0 < nk_total; g0 += nkc) {
+            const int nk = min(nkc, nk_total - g0);
+            if (c || g0) load_strip<true>(xr, xi, 0, pre, sr, si);
+            forward_rows<true>(L, xr, xi, g0, nk, pre, nullptr, 0, unused, sr, si);
+            for (int e = tid; e < nk * MRI_R; e += MRI_THREADS) {
+                const int j = e / MRI_R, kx = e - j * MRI_R;
+                const int ky = L.rowl[g0 + j];
+                const cf32 v = L.Rk[(size_t)j * MRI_RS + kx];
+                const float s = sgn(kx);
+                outr[(size_t)ky * MRI_R + kx] = s * v.x;
+                outi[(size_t)ky * MRI_R + kx] = s * v.y;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -507,6 +637,40 @@ extern "C" int mri_adjoint(const float* g, int B, int T, int R, const int32_t* r
     hipLaunchKernelGGL(k_mri_adjoint, dim3(B * T), dim3(MRI_THREADS), lds, (hipStream_t)stream, g,
                        rows, nrows, mask_frames, T, nkc, out);
     STEP_CHECK_LAUNCH("mri_adjoint");
+    return STEP_OK;
+}
+
+extern "C" int mri_forward_mc(const float* x, const float* sens, int C, int B, int T, int R,
+                              const int32_t* rows, const int32_t* nrows, int mask_frames,
+                              int max_rows, float* out, void* stream) {
+    STEP_REQUIRE(x && sens && out && C > 0, "mri_forward_mc: null pointer / C");
+    if (int rc = mri_check("mri_forward_mc", B, T, R, rows, nrows, mask_frames)) return rc;
+    const int nkc = pick_nkc(max_rows);
+    const size_t lds = mri_lds_bytes(nkc);
+    step_allow_lds((const void*)k_mri_forward_mc, lds);
+    hipLaunchKernelGGL(k_mri_forward_mc, dim3(B * T), dim3(MRI_THREADS), lds, (hipStream_t)stream, x,
+                       sens, C, rows, nrows, mask_frames, T, nkc, out);
+    STEP_CHECK_LAUNCH("mri_forward_mc");
+    return STEP_OK;
+}
+
+extern "C" int mri_loss_grad_mc(const float* x, const float* sens, int C, const float* y, int y_batch,
+                                int B, int T, int R, const int32_t* rows, const int32_t* nrows,
+                                int mask_frames, int max_rows, const float* chain_scale,
+                                float* loss_part, float* loss, float* loss_total, float* grad,
+                                void* stream) {
+    STEP_REQUIRE(x && sens && y && loss_part && loss && C > 0, "mri_loss_grad_mc: null pointer / C");
+    STEP_REQUIRE(y_batch == 1 || y_batch == B, "mri_loss_grad_mc: measurement batch %d vs B=%d", y_batch, B);
+    if (int rc = mri_check("mri_loss_grad_mc", B, T, R, rows, nrows, mask_frames)) return rc;
+    const int nkc = pick_nkc(max_rows);
+    const size_t lds = mri_lds_bytes(nkc);
+    hipStream_t s = (hipStream_t)stream;
+    step_allow_lds((const void*)k_mri_loss_grad_mc, lds);
+    hipLaunchKernelGGL(k_mri_loss_grad_mc, dim3(B * T), dim3(MRI_THREADS), lds, s, x, sens, C, y, y_batch,
+                       rows, nrows, mask_frames, T, nkc, chain_scale, loss_part, grad);
+    STEP_CHECK_LAUNCH("mri_loss_grad_mc");
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, loss_part, 0, B, T, loss, loss_total);
+    STEP_CHECK_LAUNCH("mri_loss_grad_mc (finish)");
     return STEP_OK;
 }
 

@@ -11,7 +11,7 @@ import torch
 from .. import _lib
 from .base import Operator, register_operator
 
-__all__ = ["DynamicMRI"]
+__all__ = ["DynamicMRI", "MultiCoilMRI", "birdcage_maps"]
 
 _MODES = {"same_mask": 0, "split_mask": 1, "random_split_mask": 2}
 
@@ -161,3 +161,107 @@ class DynamicMRI(Operator):
         if return_loss:
             return grad, self._loss_total
         return grad
+
+
+def birdcage_maps(coils, resolution=192, radius=1.2, dtype=torch.complex64):
+    """Smooth synthetic coil sensitivities [C, R, R] (complex): coil c sits on a circle around the
+    field of view, magnitude ~ 1 / distance, phase = the angle towards the coil; normalised so that
+    sum_c |S_c|^2 = 1 in every pixel (the usual SENSE convention)."""
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, resolution, dtype=torch.float64),
+                            torch.linspace(-1, 1, resolution, dtype=torch.float64), indexing="ij")
+    maps = []
+    for c in range(coils):
+        a = 2 * np.pi * c / coils
+        dx, dy = xx - radius * np.cos(a), yy - radius * np.sin(a)
+        maps.append(torch.polar(1.0 / torch.sqrt(dx * dx + dy * dy + 0.05), torch.atan2(dy, dx)))
+    s = torch.stack(maps)
+    return (s / s.abs().pow(2).sum(0, keepdim=True).sqrt()).to(dtype)
+
+
+class _ForwardMCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        ctx.op, ctx.dtype = op, x.dtype
+        return op._launch_forward(_f32c(x, x.device))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        # A^H g through the fused kernel: the gradient of sum |A x - y|^2 at x = 0 with y = -g / 2
+        # is 2 A^H(0 - y) = A^H g
+        op = ctx.op
+        z = torch.zeros(g.shape[0], g.shape[1], 2, op.resolution, op.resolution, device=g.device)
+        _, grad = op._launch_loss_grad(z, -0.5 * _f32c(g, g.device), True, None)
+        return grad.to(ctx.dtype), None
+
+
+@register_operator('mri_multicoil')
+class MultiCoilMRI(DynamicMRI):
+    """Multi-coil dynamic MRI, y_c = M * FFT2(fftshift(S_c * x)): NO REFERENCE COUNTERPART (the
+    reference's operator is single-coil, dynamic_mri.py:42-48); the kernel-backed operator that
+    BASELINE.json's north_star names.  ``sens``: complex [C, R, R] (or real [C, 2, R, R]); ``coils``:
+    build ``birdcage_maps(coils)`` instead.  ``__call__`` returns [B, T, C, 2, R, R]; ``loss`` /
+    ``gradient`` keep the single-coil semantics summed over coils.  With C = 1 and S = 1 every
+    result equals the single-coil operator's first-generation kernels bit for bit."""
+
+    def __init__(self, acc_factor, mode='same_mask', resolution=192, frames=12, num_acs_lines=12,
+                 sigma=0, sens=None, coils=None):
+        super().__init__(acc_factor, mode, resolution, frames, num_acs_lines, sigma)
+        if sens is None:
+            if not coils:
+                raise ValueError("mri_multicoil needs `sens` ([C, R, R] complex) or `coils`")
+            sens = birdcage_maps(int(coils), resolution)
+        sens = torch.as_tensor(sens)
+        if torch.is_complex(sens):
+            sens = torch.stack([sens.real, sens.imag], dim=1)
+        if sens.dim() != 4 or sens.shape[1] != 2 or sens.shape[2] != resolution or sens.shape[3] != resolution:
+            raise ValueError("sens must be [C, R, R] complex or [C, 2, R, R], got %s" % (tuple(sens.shape),))
+        self.sens = sens.to(torch.float32).contiguous()
+        self.coils = self.sens.shape[0]
+        self._sens_dev = {}
+
+    def _sens_on(self, device):
+        key = str(device)
+        if key not in self._sens_dev:
+            self._sens_dev[key] = self.sens.to(device)
+        return self._sens_dev[key]
+
+    def _launch_forward(self, x):
+        B, T = self._dims(x)
+        rows, nrows = self._tables(x.device)
+        out = torch.empty(B, T, self.coils, 2, self.resolution, self.resolution, device=x.device)
+        rc = _lib.lib().mri_forward_mc(x.data_ptr(), self._sens_on(x.device).data_ptr(), self.coils, B, T,
+                                       self.resolution, rows.data_ptr(), nrows.data_ptr(),
+                                       self.mask.shape[1], self._max_rows, out.data_ptr(), _lib.stream_of(x))
+        _lib.check(rc, "mri_forward_mc")
+        return out
+
+    def _launch_loss_grad(self, x, y, need_grad, chain_scale):
+        B, T = self._dims(x)
+        y = _f32c(y, x.device)
+        want = (T, self.coils, 2, self.resolution, self.resolution)
+        if y.dim() != 6 or tuple(y.shape[1:]) != want or y.shape[0] not in (1, B):
+            raise ValueError("measurement shape %s, expected [1 or %d, %s]" % (tuple(y.shape), B, want))
+        rows, nrows = self._tables(x.device)
+        part = torch.empty(B * T, device=x.device, dtype=torch.float32)
+        loss = torch.empty(B + 1, device=x.device, dtype=torch.float32)
+        grad = torch.empty_like(x) if need_grad else None
+        t0 = None
+        if self._prof is not None:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(x.device))
+        rc = _lib.lib().mri_loss_grad_mc(x.data_ptr(), self._sens_on(x.device).data_ptr(), self.coils,
+                                         y.data_ptr(), y.shape[0], B, T, self.resolution, rows.data_ptr(),
+                                         nrows.data_ptr(), self.mask.shape[1], self._max_rows,
+                                         _lib.ptr(chain_scale), part.data_ptr(), loss.data_ptr(),
+                                         loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream(x.device))
+            self._prof.setdefault("mri_loss_grad_mc", []).append((t0, t1))
+        _lib.check(rc, "mri_loss_grad_mc")
+        self._loss_total = loss[B]
+        return loss[:B], grad
+
+    def __call__(self, x):
+        return _ForwardMCFn.apply(x, self)

@@ -1,0 +1,66 @@
+"""Multi-coil dynamic MRI (mri_forward_mc / mri_loss_grad_mc; NO REFERENCE COUNTERPART, parity
+unpinned) against its oracle -- the reference's single-coil formulation applied coil by coil with
+an explicit coil sum -- and, for C = 1 with unit sensitivity, bit for bit against the single-coil
+kernels that ARE pinned to the reference."""
+import pytest
+import torch
+
+from oracle.mri_mc_oracle import MultiCoilMRIOracle
+from oracle.mri_oracle import MRIOracle
+from tests.helpers import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+CFG = dict(acc_factor=6, resolution=192, frames=12, num_acs_lines=24)
+
+
+def make(mode, **kw):
+    from step_amd.forward_operator import get_operator
+    return get_operator("mri_multicoil", mode=mode, **dict(CFG, **kw))
+
+
+@pytest.mark.parametrize("mode", ["same_mask", "split_mask"])
+def test_single_coil_unit_sensitivity_is_the_single_coil_kernel(mode, dev):
+    from step_amd.forward_operator import get_operator
+    sens = torch.ones(1, 192, 192, dtype=torch.complex64)
+    mc, sc = make(mode, sens=sens), get_operator("mri", mode=mode, **CFG)
+    sc.kernel_variant = 1                                   # the first-generation kernel
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
+    y = sc(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)) + 0.1 * torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)
+    assert torch.equal(mc(x)[:, :, 0], sc(x))
+    g1, l1 = mc.gradient(x, y.unsqueeze(2), return_loss=True)
+    g0, l0 = sc.gradient(x, y, return_loss=True)
+    assert torch.equal(g1, g0) and torch.equal(l1, l0)
+    assert torch.equal(mc.loss(x, y.unsqueeze(2)), sc.loss(x, y))
+    sc.kernel_variant = 0                                   # and the pipelined kernel to rounding
+    assert_close(g1, sc.gradient(x, y), 1e-5, "vs pipelined kernel")
+
+
+@pytest.mark.parametrize("C,mode,acc,acs", [(8, "same_mask", 6, 24), (3, "random_split_mask", 6, 24), (2, "same_mask", 2, 24)])
+def test_matches_the_coil_by_coil_oracle(C, mode, acc, acs, dev):
+    from step_amd.forward_operator import birdcage_maps
+    sens = birdcage_maps(C) * torch.polar(torch.ones(C, 1, 1), torch.linspace(0, 2, C).view(C, 1, 1))
+    op = make(mode, acc_factor=acc, num_acs_lines=acs, sens=sens)
+    orc = MultiCoilMRIOracle(acc, mode, 192, 12, acs, sens)
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(2, 12, 2, 192, 192, generator=gen)
+    y = orc(torch.randn(2, 12, 2, 192, 192, generator=gen)) + 0.1 * torch.randn(2, 12, C, 2, 192, 192, generator=gen)
+    assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    assert_close(op.loss(x.to(dev), y.to(dev)), orc.loss(x, y), RTOL, "per-chain loss")
+    # one measurement for all chains broadcasts
+    g1 = op.gradient(x.to(dev), y[:1].to(dev))
+    assert_close(g1[1], orc.gradient(x[1:], y[:1])[0], RTOL, "broadcast measurement")
+    # autograd routes: loss and A(x)
+    xr = x.to(dev).clone().requires_grad_(True)
+    w = torch.tensor([0.5, -2.0], device=dev)
+    ga = torch.autograd.grad((op.loss(xr, y.to(dev)) * w).sum(), xr)[0]
+    assert_close(ga, g_got * w.view(-1, 1, 1, 1, 1), 1e-5, "autograd through loss")
+    gk = torch.randn(2, 12, C, 2, 192, 192, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    want = torch.autograd.grad((orc(xo) * gk).sum(), xo)[0]
+    got = torch.autograd.grad((op(xr) * gk.to(dev)).sum(), xr)[0]
+    assert_close(got, want, RTOL, "adjoint (vector-Jacobian product of A)")

@@ -140,3 +140,20 @@ def test_latent_daps_oracle_matches_reference_mri(golden):
             model, t(d["z_start"]), orc, mri_measurement(d))
     assert not tape.n
     close(out, d["result"], 1e-4)
+
+
+def test_multicoil_oracle_reduces_to_the_pinned_single_coil_oracle():
+    """The multi-coil oracle has no reference counterpart; its C = 1, S = 1 case IS the pinned
+    single-coil oracle, bit for bit, and its coil sum is explicit."""
+    from oracle.mri_mc_oracle import MultiCoilMRIOracle
+    sens = torch.ones(1, 192, 192, dtype=torch.complex64)
+    mc, sc = MultiCoilMRIOracle(6, "same_mask", 192, 12, 24, sens), MRIOracle(6, "same_mask", 192, 12, 24)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 12, 2, 192, 192, generator=g)
+    y = torch.randn(1, 12, 2, 192, 192, generator=g)
+    assert torch.equal(mc(x)[:, :, 0], sc(x))
+    assert torch.equal(mc.loss(x, y.unsqueeze(2)), sc.loss(x, y))
+    s2 = torch.stack([sens[0], 2j * sens[0]])
+    m2 = MultiCoilMRIOracle(6, "same_mask", 192, 12, 24, s2)
+    want = sc.loss(x, y) + (sc(2 * torch.stack([-x[:, :, 1], x[:, :, 0]], 2)) - y).pow(2).flatten(1).sum(-1)
+    close(m2.loss(x, torch.stack([y, y], 2)), want, 1e-6)
