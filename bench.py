@@ -45,7 +45,9 @@ def parse():
     # (the first ~15 ms of MFMA work run 20 % slower than steady state) inside the warm-up
     p.add_argument("--steps", type=int, default=400)
     p.add_argument("--warmup", type=int, default=100)
-    p.add_argument("--task", default="blackhole", choices=["blackhole", "mri"])
+    p.add_argument("--task", default="blackhole", choices=["blackhole", "mri", "mri_radial"])
+    p.add_argument("--coils", type=int, default=0,
+                   help="--task mri: C > 0 runs the multi-coil operator (no reference counterpart)")
     p.add_argument("--batch", type=int, default=None, help="chains per GPU (default: blackhole 64, mri 256)")
     p.add_argument("--path", default="auto", choices=["auto", "sep3", "sep", "dense"])
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,12 +196,27 @@ def main():
         x = torch.rand(B, 64, 1, 256, 256, device=dev, generator=gen) * 2 - 1
         y = op(torch.rand(1, 64, 1, 256, 256, device=dev, generator=gen) * 2 - 1)
         workload = "blackhole operator loss fwd + adjoint, 64x1x256x256, 8 stations F=28 K_cp=1344 K_ca=1280"
-    else:
+    elif a.task == "mri_radial":
         from step_amd.forward_operator import get_operator
-        op = get_operator("mri", acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+        op = get_operator("mri_radial", spokes=32, resolution=192, frames=12)
+        B = a.batch or 64
         x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
         y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
-        workload = "mri operator loss fwd + adjoint, 12x2x192x192, acc 6 / 24 ACS same_mask"
+        workload = ("radial mri operator (gridding NUFFT, no reference counterpart) loss fwd + adjoint, "
+                    "12x2x192x192, 32 golden-angle spokes x 192 per frame")
+    else:
+        from step_amd.forward_operator import get_operator
+        cfg = dict(acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+        if a.coils > 0:
+            op = get_operator("mri_multicoil", coils=a.coils, **cfg)
+            B = a.batch or 64
+            workload = "multi-coil mri operator (%d coils, no reference counterpart) loss fwd + adjoint, " \
+                       "12x2x192x192, acc 6 / 24 ACS same_mask" % a.coils
+        else:
+            op = get_operator("mri", **cfg)
+            workload = "mri operator loss fwd + adjoint, 12x2x192x192, acc 6 / 24 ACS same_mask"
+        x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
+        y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
 
     def barrier():
         if dist is not None:
@@ -272,6 +289,23 @@ def main():
                             algorithmic="4*T*F*H*W flop per chain per direction x %d chains" % B,
                             kernels_ms=kern,
                             other={k: v["tflops"] for k, v in per.items() if k != dom})
+        elif a.task == "mri_radial":
+            ms = kern["nufft_loss_grad"]
+            byts = (16.0 * 12 * 192 * 192 + 8.0 * 12 * op.J) * B     # read x, write grad, read the samples
+            gbs = byts / (ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="nufft step (pad, FFT2 384^2, interp, spread, IFFT2, crop)",
+                        achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        algorithmic="(16*T*R*R + 8*T*J) bytes per chain x %d chains; the oversampled grids "
+                                    "(4 x 8*G*G bytes per frame through HBM) are overhead of this design" % B,
+                        kernels_ms=kern)
+        elif a.coils > 0:
+            ms = kern["mri_loss_grad_mc"]
+            byts = (16.0 + 8.0 * a.coils) * 12 * 192 * 192 * B       # read x, write grad, read y of C coils
+            gbs = byts / (ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel="mri_loss_grad_mc", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=gbs / HBM_PEAK_GBS, traffic=None,
+                        algorithmic="(16 + 8*C)*T*R*R bytes per chain x %d chains, C = %d" % (B, a.coils),
+                        kernels_ms=kern)
         else:
             byts = 24.0 * 12 * 192 * 192 * B                  # read x, read y, write grad
             gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
@@ -290,11 +324,15 @@ def main():
         # BASELINE.json's second metric, derived: Langevin steps per posterior sample at the shipped
         # configs; operator work only, the prior network is not in this bench
         per_sample = 1500 if a.task == "blackhole" else 1060
+        if a.coils > 0 or a.task == "mri_radial":
+            out["config"]["reference_counterpart"] = False
         out["derived"] = dict(samples_per_hour_operator_only=3600.0 * out["value"] / per_sample,
                               langevin_steps_per_sample=per_sample)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_blackhole(tab, a.cpu_reps) if a.task == "blackhole"
-                                   else cpu_baseline_mri(a.cpu_reps * 4))
+            if a.task == "blackhole":
+                out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)
+            elif a.task == "mri" and a.coils == 0:
+                out["cpu_baseline"] = cpu_baseline_mri(a.cpu_reps * 4)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -276,6 +276,43 @@ int mri_loss_grad_mc(const float* x, const float* sens, int C, const float* y, i
                      int max_rows, const float* chain_scale, float* loss_part, float* loss,
                      float* loss_total, float* grad, void* stream);
 
+/* ------------------------------------------------------------------ non-uniform sampling (gridding)
+ * NO REFERENCE COUNTERPART: the reference samples k-space on Cartesian rows only
+ * (dynamic_mri.py:42-48); pynfft is an install line (README.md:28).  BASELINE.json's north_star
+ * names a gridding kernel for the non-uniform path.  These are the kernels around the oversampled
+ * FFT of a NUFFT (G = 2 R, separable Kaiser-Bessel kernel of width W <= 8, per-sample weights
+ * tabulated on the host); the FFT itself is a library FFT called by the host layer between them.
+ *   type 2 (image -> samples):  nufft_pad_apod -> FFT2 (G x G) -> nufft_interp
+ *   type 1 (samples -> image):  nufft_spread   -> unnormalised IFFT2 -> nufft_crop_apod
+ * Pixel n has the centred coordinate n - R/2; a sample at kappa cycles per field of view is the
+ * sum over pixels of x[n] exp(-2 pi i kappa . (n - R/2) / R).  Grids are complex64 [frames][G][G];
+ * sample arrays complex64 [frames][J]; frames = B * T; the trajectory may differ per frame t
+ * (traj_frames = T) or be shared (1).  All plan tables are DEVICE pointers. */
+typedef struct {
+    int32_t R, G, W, J, traj_frames;
+    const int32_t* ix0;        /* [traj_frames][J] first grid column of a sample's W x W footprint (may be negative: wraps) */
+    const int32_t* iy0;
+    const float* wx;           /* [traj_frames][J][W] kernel weights along x */
+    const float* wy;
+    const int32_t* tile_ptr;   /* [traj_frames][(G/16)^2 + 1] samples touching each 16 x 16 grid tile (CSR) */
+    const int32_t* tile_ent;   /* sample ids, ascending within a tile */
+    const int64_t* tile_base;  /* [traj_frames] offset of a trajectory frame's list in tile_ent */
+    const float* apod;         /* [R] de-apodisation per axis: 1 / (kernel transform at pixel n) */
+} nufft_plan_t;
+
+int nufft_interp_blocks(int J);     /* loss_part holds frames * nufft_interp_blocks(J) floats */
+int nufft_pad_apod(const float* x, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,
+                   void* stream);
+/* out = interpolated samples, or with y_c64 != NULL: res_scale * (samples - y) and, with loss !=
+ * NULL, loss[b] = sum |samples - y|^2 (loss_total = their sum, may be NULL). */
+int nufft_interp(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                 const float* y_c64, int y_batch, float res_scale, float* out_c64, float* loss_part,
+                 float* loss, float* loss_total, void* stream);
+int nufft_spread(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,
+                 void* stream);
+int nufft_crop_apod(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                    const float* chain_scale, float out_scale, float* out, void* stream);
+
 /* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
  * the reference.  Same arguments, kernels and results as mri_loss_grad(variant = 0); the

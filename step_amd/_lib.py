@@ -42,6 +42,12 @@ class bh_step_ws_t(C.Structure):
     _fields_ = [("vis_c64", c_p), ("flux", c_p), ("dcp", c_p), ("dca", c_p), ("S", c_p)]
 
 
+class nufft_plan_t(C.Structure):
+    _fields_ = [("R", C.c_int32), ("G", C.c_int32), ("W", C.c_int32), ("J", C.c_int32), ("traj_frames", C.c_int32),
+                ("ix0", c_p), ("iy0", c_p), ("wx", c_p), ("wy", c_p), ("tile_ptr", c_p), ("tile_ent", c_p),
+                ("tile_base", c_p), ("apod", c_p)]
+
+
 class mcmc_params_t(C.Structure):
     _fields_ = [("inv_tau2", c_f), ("inv_sigma2", c_f), ("lr", c_f), ("sqrt_lr", c_f),
                 ("sqrt_2lr", c_f), ("momentum", c_f), ("noise_scale", c_f), ("algo", C.c_int32)]
@@ -85,6 +91,11 @@ SIGNATURES = {
     "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                c_p, c_p, c_p]),
+    "nufft_interp_blocks": (c_i, [c_i]),
+    "nufft_pad_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
+    "nufft_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "nufft_spread": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
+    "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                    c_p, c_p]),
     "mcmc_update_philox": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_i64,

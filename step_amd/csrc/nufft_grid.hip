@@ -1,0 +1,273 @@
+// Non-uniform (radial) k-space sampling by gridding: the kernels around the oversampled FFT of a
+// NUFFT.  NO REFERENCE COUNTERPART: the reference's MRI operator is Cartesian
+// (forward_operator/dynamic_mri.py:42-48) and `pynfft` is only an install line (README.md:28);
+// BASELINE.json's north_star names "the non-uniform-sampling path ... reimplemented as a gridding
+// kernel".  Oracle: the direct non-uniform DFT in fp64 (oracle/nufft_oracle.py).
+//
+//   forward  (type 2):  x [R x R]  --pad + deapodise-->  [G x G]  --FFT2-->  --interpolate-->  y_j
+//   adjoint  (type 1):  r_j  --spread (gridding)-->  [G x G]  --unnormalised IFFT2-->  --crop + deapodise-->  [R x R]
+//
+// G = 2 R oversampled grid, separable Kaiser-Bessel kernel of width W (<= 8) whose per-sample
+// weights and first grid index are tabulated once per trajectory on the host (fp64 -> fp32), so
+// the kernels do no transcendental work.  Pixel n of an axis has the centred coordinate n - R/2
+// and sits at grid index (n - R/2) mod G; a sample at kappa cycles per field of view sits at grid
+// coordinate 2 kappa.  The FFT between the two halves is a plain library FFT (hipFFT through
+// torch.fft on the same stream) -- the gridding, interpolation and apodisation are these kernels.
+//
+// Spreading is a GATHER, not a scatter: the host bins the samples by 16 x 16 grid tile (every tile
+// a sample's W x W footprint touches); one workgroup owns a tile of a frame, stages the tile's
+// samples through LDS, and every thread sums the contributions to its own grid point in list
+// order -- no atomics, bitwise reproducible, the grid is written exactly once, coalesced.
+#include "common.h"
+
+#define NU_TILE 16
+#define NU_WMAX 8
+#define NU_CHUNK 64          // samples staged in LDS at a time
+
+struct NuPlan {
+    int R, G, W, J, traj_frames, tiles;       // tiles per side = G / NU_TILE
+    const int32_t* ix0;                       // [traj_frames][J] first grid column of the footprint (mod G applied later)
+    const int32_t* iy0;
+    const float* wx;                          // [traj_frames][J][W]
+    const float* wy;
+    const int32_t* tile_ptr;                  // [traj_frames][tiles*tiles + 1]
+    const int32_t* tile_ent;                  // [traj_frames][...] sample ids, ascending per tile
+    const int64_t* tile_base;                 // [traj_frames] offset of a trajectory frame's entries in tile_ent
+    const float* apod;                        // [R] 1 / kernel transform at pixel n (per axis)
+};
+
+__device__ __forceinline__ int nu_wrap(int i, int G) { return i < 0 ? i + G : (i >= G ? i - G : i); }
+
+// grid[f][gy][gx] = apod[y] apod[x] (x_re + i x_im)[y][x] at (y - R/2, x - R/2) mod G, zero elsewhere
+__global__ __launch_bounds__(256) void k_nufft_pad_apod(const float* __restrict__ x, NuPlan p,
+                                                        float2* __restrict__ grid) {
+    const int f = blockIdx.y, G = p.G, R = p.R, h = R / 2;
+    const size_t fsz = (size_t)R * R;
+    const float* xr = x + (size_t)f * 2 * fsz;
+    const float* xi = xr + fsz;
+    float2* g = grid + (size_t)f * G * G;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < G * G; e += gridDim.x * 256) {
+        const int gy = e / G, gx = e - gy * G;
+        // grid index -> pixel: indices [0, h) hold pixels h .. R-1, indices [G-h, G) hold pixels 0 .. h-1
+        const int py = gy < h ? gy + h : (gy >= G - h ? gy - (G - h) : -1);
+        const int px = gx < h ? gx + h : (gx >= G - h ? gx - (G - h) : -1);
+        float2 v = make_float2(0.f, 0.f);
+        if (py >= 0 && px >= 0) {
+            const float a = p.apod[py] * p.apod[px];
+            v = make_float2(a * xr[py * R + px], a * xi[py * R + px]);
+        }
+        g[e] = v;
+    }
+}
+
+// out[f][j] = sum_{a,b} wy[j][a] wx[j][b] grid[f][iy0+a][ix0+b]; with y != null the residual
+// against the measurement is formed in the same pass: out = res_scale * (yhat - y) and the block's
+// sum |yhat - y|^2 goes to loss_part[f][blockIdx.x]
+__global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__ grid, NuPlan p, int T,
+                                                      const float2* __restrict__ y, int y_batch,
+                                                      float res_scale, float2* __restrict__ out,
+                                                      float* __restrict__ loss_part) {
+    __shared__ float red[8];
+    const int f = blockIdx.y, b = f / T, t = f - b * T, tf = p.traj_frames == 1 ? 0 : t;
+    const int j = blockIdx.x * 256 + threadIdx.x, G = p.G, W = p.W;
+    const float2* g = grid + (size_t)f * G * G;
+    float acc = 0.f;
+    if (j < p.J) {
+        const size_t sj = (size_t)tf * p.J + j;
+        const int x0 = p.ix0[sj], y0 = p.iy0[sj];
+        const float* wx = p.wx + sj * W;
+        const float* wy = p.wy + sj * W;
+        float wxr[NU_WMAX];
+        int cx[NU_WMAX];
+#pragma unroll
+        for (int k = 0; k < NU_WMAX; ++k) {
+            wxr[k] = k < W ? wx[k] : 0.f;
+            cx[k] = nu_wrap(x0 + (k < W ? k : 0), G);
+        }
+        float sr = 0.f, si = 0.f;
+        for (int a = 0; a < W; ++a) {
+            const float2* row = g + (size_t)nu_wrap(y0 + a, G) * G;
+            float rr = 0.f, ri = 0.f;
+#pragma unroll
+            for (int k = 0; k < NU_WMAX; ++k)
+                if (k < W) {
+                    const float2 v = row[cx[k]];
+                    rr += wxr[k] * v.x;
+                    ri += wxr[k] * v.y;
+                }
+            const float w = wy[a];
+            sr += w * rr;
+            si += w * ri;
+        }
+        float2 o = make_float2(sr, si);
+        if (y) {
+            const float2 m = y[((size_t)(y_batch > 1 ? b : 0) * T + t) * p.J + j];
+            const float dr = sr - m.x, di = si - m.y;
+            acc = dr * dr + di * di;
+            o = make_float2(res_scale * dr, res_scale * di);
+        }
+        out[(size_t)f * p.J + j] = o;
+    }
+    if (loss_part) {
+        const float tot = block_sum(acc, red);
+        if (threadIdx.x == 0) loss_part[(size_t)f * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// grid[f][gy][gx] = sum over the tile's samples j (ascending) of wy[j][gy - iy0] wx[j][gx - ix0] v[f][j]
+__global__ __launch_bounds__(NU_TILE * NU_TILE) void k_nufft_spread(const float2* __restrict__ vals, NuPlan p,
+                                                                     int T, float2* __restrict__ grid) {
+    __shared__ int s_x0[NU_CHUNK], s_y0[NU_CHUNK];
+    __shared__ float s_wx[NU_CHUNK][NU_WMAX], s_wy[NU_CHUNK][NU_WMAX];
+    __shared__ float2 s_v[NU_CHUNK];
+    const int f = blockIdx.y, t = f % T, tf = p.traj_frames == 1 ? 0 : t;
+    const int tile = blockIdx.x, ty = tile / p.tiles, tx = tile - ty * p.tiles;
+    const int tid = threadIdx.x, ly = tid / NU_TILE, lx = tid - ly * NU_TILE;
+    const int gy = ty * NU_TILE + ly, gx = tx * NU_TILE + lx, G = p.G, W = p.W;
+    const int32_t* ptr = p.tile_ptr + (size_t)tf * (p.tiles * p.tiles + 1);
+    const int32_t* ent = p.tile_ent + p.tile_base[tf];
+    const int e0 = ptr[tile], e1 = ptr[tile + 1];
+    float ar = 0.f, ai = 0.f;
+    for (int c0 = e0; c0 < e1; c0 += NU_CHUNK) {
+        const int n = min(NU_CHUNK, e1 - c0);
+        __syncthreads();
+        if (tid < n) {
+            const int j = ent[c0 + tid];
+            const size_t sj = (size_t)tf * p.J + j;
+            s_x0[tid] = p.ix0[sj];
+            s_y0[tid] = p.iy0[sj];
+            s_v[tid] = vals[(size_t)f * p.J + j];
+        }
+        for (int u = tid; u < n * W; u += NU_TILE * NU_TILE) {
+            const int q = u / W, k = u - q * W;
+            const size_t sj = (size_t)tf * p.J + ent[c0 + q];
+            s_wx[q][k] = p.wx[sj * W + k];
+            s_wy[q][k] = p.wy[sj * W + k];
+        }
+        __syncthreads();
+        for (int q = 0; q < n; ++q) {
+            // offset of this grid point inside the sample's footprint, on the torus
+            int dy = gy - s_y0[q], dx = gx - s_x0[q];
+            dy = dy < 0 ? dy + G : (dy >= G ? dy - G : dy);
+            dx = dx < 0 ? dx + G : (dx >= G ? dx - G : dx);
+            if (dy < W && dx < W) {
+                const float w = s_wy[q][dy] * s_wx[q][dx];
+                ar += w * s_v[q].x;
+                ai += w * s_v[q].y;
+            }
+        }
+    }
+    grid[((size_t)f * G + gy) * G + gx] = make_float2(ar, ai);
+}
+
+// out[f][0/1][y][x] = scale * apod[y] apod[x] * Re/Im grid[f][(y - R/2) mod G][(x - R/2) mod G]
+__global__ __launch_bounds__(256) void k_nufft_crop_apod(const float2* __restrict__ grid, NuPlan p, int T,
+                                                         const float* __restrict__ chain_scale,
+                                                         float out_scale, float* __restrict__ out) {
+    const int f = blockIdx.y, G = p.G, R = p.R, h = R / 2;
+    const float cs = out_scale * (chain_scale ? chain_scale[f / T] : 1.f);
+    const float2* g = grid + (size_t)f * G * G;
+    float* outr = out + (size_t)f * 2 * R * R;
+    float* outi = outr + (size_t)R * R;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < R * R; e += gridDim.x * 256) {
+        const int py = e / R, px = e - py * R;
+        const int gy = py >= h ? py - h : py + G - h, gx = px >= h ? px - h : px + G - h;
+        const float a = cs * p.apod[py] * p.apod[px];
+        const float2 v = g[(size_t)gy * G + gx];
+        outr[e] = a * v.x;
+        outi[e] = a * v.y;
+    }
+}
+
+// loss[b] = sum of the chain's partials in a fixed order; total = sum_b loss[b]
+__global__ __launch_bounds__(256) void k_nufft_loss_finish(const float* __restrict__ part, int per_chain, int B,
+                                                           float* __restrict__ loss, float* __restrict__ total) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float mine = 0.f;
+    for (int b = tid; b < B; b += 256) {
+        const float* q = part + (size_t)b * per_chain;
+        float s = 0.f;
+        for (int i = 0; i < per_chain; ++i) s += q[i];
+        loss[b] = s;
+        mine += s;
+    }
+    red[tid] = mine;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (total && tid == 0) *total = red[0];
+}
+
+static int nu_check(const char* who, const nufft_plan_t* p, int nframes, int T) {
+    STEP_REQUIRE(p, "%s: null plan", who);
+    STEP_REQUIRE(nframes > 0 && T > 0 && nframes % T == 0, "%s: %d frames, T = %d", who, nframes, T);
+    STEP_REQUIRE(p->R > 0 && p->R % 2 == 0 && p->G == 2 * p->R && p->G % NU_TILE == 0,
+                 "%s: need an even R and G = 2 R divisible by %d (R=%d G=%d)", who, NU_TILE, p->R, p->G);
+    STEP_REQUIRE(p->W >= 2 && p->W <= NU_WMAX && p->J > 0, "%s: kernel width %d (2..%d), J = %d", who, p->W, NU_WMAX, p->J);
+    STEP_REQUIRE(p->traj_frames == 1 || p->traj_frames == T, "%s: traj_frames = %d must be 1 or T = %d", who, p->traj_frames, T);
+    STEP_REQUIRE(p->ix0 && p->iy0 && p->wx && p->wy && p->tile_ptr && p->tile_ent && p->tile_base && p->apod,
+                 "%s: null plan table", who);
+    return STEP_OK;
+}
+
+static NuPlan nu_plan(const nufft_plan_t* p) {
+    return NuPlan{p->R, p->G, p->W, p->J, p->traj_frames, p->G / NU_TILE, p->ix0, p->iy0, p->wx, p->wy,
+                  p->tile_ptr, p->tile_ent, p->tile_base, p->apod};
+}
+
+extern "C" int nufft_interp_blocks(int J) { return (J + 255) / 256; }
+
+extern "C" int nufft_pad_apod(const float* x, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,
+                              void* stream) {
+    STEP_REQUIRE(x && grid_c64, "nufft_pad_apod: null pointer");
+    if (int rc = nu_check("nufft_pad_apod", plan, nframes, T)) return rc;
+    hipLaunchKernelGGL(k_nufft_pad_apod, dim3(64, nframes), dim3(256), 0, (hipStream_t)stream, x, nu_plan(plan),
+                       (float2*)grid_c64);
+    STEP_CHECK_LAUNCH("nufft_pad_apod");
+    return STEP_OK;
+}
+
+extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                            const float* y_c64, int y_batch, float res_scale, float* out_c64,
+                            float* loss_part, float* loss, float* loss_total, void* stream) {
+    STEP_REQUIRE(grid_c64 && out_c64, "nufft_interp: null pointer");
+    if (int rc = nu_check("nufft_interp", plan, nframes, T)) return rc;
+    const int B = nframes / T;
+    STEP_REQUIRE(!y_c64 || y_batch == 1 || y_batch == B, "nufft_interp: measurement batch %d vs B=%d", y_batch, B);
+    STEP_REQUIRE(!loss || (y_c64 && loss_part), "nufft_interp: the loss needs the measurement and loss_part");
+    const int nblk = nufft_interp_blocks(plan->J);
+    hipLaunchKernelGGL(k_nufft_interp, dim3(nblk, nframes), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)grid_c64, nu_plan(plan), T, (const float2*)y_c64, y_batch, res_scale,
+                       (float2*)out_c64, y_c64 ? loss_part : nullptr);
+    STEP_CHECK_LAUNCH("nufft_interp");
+    if (loss) {
+        hipLaunchKernelGGL(k_nufft_loss_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_part, T * nblk, B,
+                           loss, loss_total);
+        STEP_CHECK_LAUNCH("nufft_interp (loss)");
+    }
+    return STEP_OK;
+}
+
+extern "C" int nufft_spread(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan,
+                            float* grid_c64, void* stream) {
+    STEP_REQUIRE(vals_c64 && grid_c64, "nufft_spread: null pointer");
+    if (int rc = nu_check("nufft_spread", plan, nframes, T)) return rc;
+    const NuPlan p = nu_plan(plan);
+    hipLaunchKernelGGL(k_nufft_spread, dim3(p.tiles * p.tiles, nframes), dim3(NU_TILE * NU_TILE), 0,
+                       (hipStream_t)stream, (const float2*)vals_c64, p, T, (float2*)grid_c64);
+    STEP_CHECK_LAUNCH("nufft_spread");
+    return STEP_OK;
+}
+
+extern "C" int nufft_crop_apod(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                               const float* chain_scale, float out_scale, float* out, void* stream) {
+    STEP_REQUIRE(grid_c64 && out, "nufft_crop_apod: null pointer");
+    if (int rc = nu_check("nufft_crop_apod", plan, nframes, T)) return rc;
+    hipLaunchKernelGGL(k_nufft_crop_apod, dim3(32, nframes), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)grid_c64, nu_plan(plan), T, chain_scale, out_scale, out);
+    STEP_CHECK_LAUNCH("nufft_crop_apod");
+    return STEP_OK;
+}

@@ -1,0 +1,241 @@
+"""Dynamic MRI with NON-UNIFORM (radial) k-space sampling on the gridding kernels
+(step_amd/csrc/nufft_grid.hip).  NO REFERENCE COUNTERPART: the reference's MRI operator samples
+Cartesian rows (forward_operator/dynamic_mri.py:42-48) and `pynfft` appears only as an install
+line (README.md:28); BASELINE.json's north_star names the non-uniform path as a gridding kernel.
+Parity is therefore UNPINNED; the oracle is the direct non-uniform DFT in fp64
+(oracle/nufft_oracle.py), which the operator matches to the accuracy of the Kaiser-Bessel design
+(width 6, oversampling 2: ~1e-5 relative, asserted at 1e-4 in tests/test_gpu_nufft.py).
+
+    y[b, t, j] = sum_n (x_re + i x_im)[b, t, n] exp(-2 pi i kappa[t, j] . (n - R/2) / R)
+
+with kappa in cycles per field of view.  Same operator interface as the other tasks
+(``__call__``, ``loss``, ``gradient``, autograd through ``loss``); registry name ``'mri_radial'``.
+The default trajectory is golden-angle radial: ``spokes`` spokes of ``R`` read-out points per
+frame, the angle advancing by pi (sqrt(5) - 1) / 2 from spoke to spoke across the frames.
+The hand-written part is the gridding: pad + de-apodise, interpolate (+ residual + loss),
+spread (a deterministic gather over host-binned tiles), crop + de-apodise.  The oversampled FFT
+between them is hipFFT through ``torch.fft`` on the same stream (a plain library FFT)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .base import Operator, register_operator
+
+__all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
+
+_TILE = 16
+
+
+def golden_angle_radial(frames, spokes, resolution):
+    """kappa [frames, spokes * resolution, 2] = (kx, ky) in cycles per field of view."""
+    rho = np.arange(resolution, dtype=np.float64) - resolution / 2
+    s = np.arange(frames * spokes, dtype=np.float64).reshape(frames, spokes)
+    th = s * (math.pi * (math.sqrt(5.0) - 1.0) / 2.0)
+    kx = rho[None, None, :] * np.cos(th)[..., None]
+    ky = rho[None, None, :] * np.sin(th)[..., None]
+    return np.stack([kx, ky], -1).reshape(frames, spokes * resolution, 2)
+
+
+def _kb(d, W, beta):
+    a = 1.0 - (2.0 * d / W) ** 2
+    return np.where(a >= 0, np.i0(beta * np.sqrt(np.maximum(a, 0.0))), 0.0) / np.i0(beta)
+
+
+def kb_plan(kappa, R, W=6):
+    """Host tables of the gridding plan for a trajectory ``kappa`` [Tt, J, 2] (fp64 arithmetic):
+    first grid index and W separable Kaiser-Bessel weights per sample and axis on the G = 2 R
+    grid (beta from Beatty et al. 2005 for oversampling 2), the samples binned by 16 x 16 grid tile,
+    and the de-apodisation 1 / phi_hat at the pixel positions."""
+    kappa = np.asarray(kappa, dtype=np.float64)
+    Tt, J, _ = kappa.shape
+    G, sigma = 2 * R, 2.0
+    beta = math.pi * math.sqrt((W / sigma) ** 2 * (sigma - 0.5) ** 2 - 0.8)
+    if np.abs(kappa).max() > R / 2:
+        raise ValueError("sample frequencies must lie in [-R/2, R/2] cycles per field of view")
+    u = sigma * kappa                                               # grid coordinates
+    i0 = np.ceil(u - W / 2.0).astype(np.int64)                      # [Tt, J, 2]
+    off = i0[..., None] + np.arange(W) - u[..., None]               # [Tt, J, 2, W] in [-W/2, W/2)
+    w = _kb(off, W, beta)
+    nt = G // _TILE
+    ptrs, ents, base = [], [], [0]
+    for t in range(Tt):
+        lists = [[] for _ in range(nt * nt)]
+        for j in range(J):
+            xs = sorted({((i0[t, j, 0] + k) % G) // _TILE for k in range(W)})
+            ys = sorted({((i0[t, j, 1] + k) % G) // _TILE for k in range(W)})
+            for ty in ys:
+                for tx in xs:
+                    lists[ty * nt + tx].append(j)
+        ptr = np.zeros(nt * nt + 1, np.int32)
+        ptr[1:] = np.cumsum([len(l) for l in lists])
+        ptrs.append(ptr)
+        ents.append(np.array([j for l in lists for j in l], dtype=np.int32))
+        base.append(base[-1] + len(ents[-1]))
+    # continuous transform of the kernel at nu = (n - R/2) / G cycles per grid sample
+    d = np.linspace(-W / 2.0, W / 2.0, 4001)
+    nu = (np.arange(R) - R / 2) / G
+    phat = np.trapezoid(_kb(d, W, beta)[None, :] * np.cos(2 * math.pi * nu[:, None] * d[None, :]), d, axis=1)
+    return dict(R=R, G=G, W=W, J=J, traj_frames=Tt,
+                ix0=i0[..., 0].astype(np.int32), iy0=i0[..., 1].astype(np.int32),
+                wx=w[:, :, 0].astype(np.float32), wy=w[:, :, 1].astype(np.float32),
+                tile_ptr=np.stack(ptrs), tile_ent=np.concatenate(ents), tile_base=np.array(base[:-1], np.int64),
+                apod=(1.0 / phat).astype(np.float32))
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, y, unit_upstream):
+        need = ctx.needs_input_grad[0]
+        loss, _, grad = op._loss_grad(x.detach(), y, need, want_total=False)
+        ctx.dtype, ctx.unit = x.dtype, bool(unit_upstream)
+        if need:
+            ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        if not ctx.unit:
+            grad = grad * grad_loss.to(grad.dtype).view(-1, 1, 1, 1, 1)
+        return grad.to(ctx.dtype), None, None, None
+
+
+class _ForwardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        ctx.op, ctx.dtype = op, x.dtype
+        return op._type2(x.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return ctx.op._type1(g.detach(), 1.0).to(ctx.dtype), None
+
+
+@register_operator('mri_radial')
+class RadialMRI(Operator):
+    def __init__(self, spokes=32, resolution=192, frames=12, sigma=0, kernel_width=6, trajectory=None,
+                 max_chunk=64):
+        super().__init__(sigma)
+        self.resolution, self.frames, self.spokes = resolution, frames, spokes
+        kappa = golden_angle_radial(frames, spokes, resolution) if trajectory is None \
+            else np.asarray(trajectory, dtype=np.float64)
+        if kappa.ndim == 2:
+            kappa = kappa[None]
+        if kappa.shape[0] not in (1, frames) or kappa.shape[-1] != 2:
+            raise ValueError("trajectory must be [J, 2] or [1 or frames, J, 2], got %s" % (kappa.shape,))
+        self.trajectory = kappa
+        self._host = kb_plan(kappa, resolution, kernel_width)
+        self.J = self._host["J"]
+        self.max_chunk = max_chunk        # chains per pass: the oversampled grids are 8 G^2 bytes per frame
+        self._dev = {}
+
+    _prof = None
+
+    def _plan(self, device):
+        key = str(device)
+        if key not in self._dev:
+            h = self._host
+            t = {k: torch.from_numpy(np.ascontiguousarray(h[k])).to(device)
+                 for k in ("ix0", "iy0", "wx", "wy", "tile_ptr", "tile_ent", "tile_base", "apod")}
+            plan = _lib.nufft_plan_t(h["R"], h["G"], h["W"], h["J"], h["traj_frames"],
+                                     *[t[k].data_ptr() for k in ("ix0", "iy0", "wx", "wy", "tile_ptr",
+                                                                 "tile_ent", "tile_base", "apod")])
+            self._dev[key] = (plan, t)
+        return self._dev[key][0]
+
+    def _check(self, x):
+        R = self.resolution
+        if x.dim() != 5 or tuple(x.shape[1:]) != (self.frames, 2, R, R):
+            raise ValueError("mri_radial expects [B, %d, 2, %d, %d], got %s" % (self.frames, R, R, tuple(x.shape)))
+        return x.to(torch.float32).contiguous()
+
+    def _grid_fft(self, x):
+        """pad + de-apodise -> FFT2 on the oversampled grid: [B, T, G, G] complex64."""
+        B, T, G = x.shape[0], self.frames, 2 * self.resolution
+        grid = torch.empty(B, T, G, G, device=x.device, dtype=torch.complex64)
+        rc = _lib.lib().nufft_pad_apod(x.data_ptr(), B * T, T, C.byref(self._plan(x.device)), grid.data_ptr(),
+                                       _lib.stream_of(x))
+        _lib.check(rc, "nufft_pad_apod")
+        return torch.fft.fft2(grid)
+
+    def _type2(self, x):
+        """-> samples [B, T, J, 2] (Re, Im)."""
+        x = self._check(x)
+        outs = []
+        for i in range(0, x.shape[0], self.max_chunk):
+            xc = x[i:i + self.max_chunk]
+            Xg = self._grid_fft(xc)
+            out = torch.empty(xc.shape[0], self.frames, self.J, 2, device=x.device, dtype=torch.float32)
+            rc = _lib.lib().nufft_interp(Xg.data_ptr(), xc.shape[0] * self.frames, self.frames,
+                                         C.byref(self._plan(x.device)), None, 1, 1.0, out.data_ptr(), None,
+                                         None, None, _lib.stream_of(x))
+            _lib.check(rc, "nufft_interp")
+            outs.append(out)
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def _type1(self, vals, out_scale, chain_scale=None):
+        """samples [B, T, J, 2] -> image [B, T, 2, R, R] (the exact adjoint of _type2)."""
+        vals = vals.to(torch.float32).contiguous()
+        B, T, R, G = vals.shape[0], self.frames, self.resolution, 2 * self.resolution
+        out = torch.empty(B, T, 2, R, R, device=vals.device, dtype=torch.float32)
+        L, plan, st = _lib.lib(), self._plan(vals.device), _lib.stream_of(vals)
+        for i in range(0, B, self.max_chunk):
+            vc = vals[i:i + self.max_chunk]
+            n = vc.shape[0]
+            grid = torch.empty(n, T, G, G, device=vals.device, dtype=torch.complex64)
+            _lib.check(L.nufft_spread(vc.data_ptr(), n * T, T, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
+            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse
+            cs = None if chain_scale is None else chain_scale[i:i + n].contiguous()
+            _lib.check(L.nufft_crop_apod(Z.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
+                                         out[i:i + n].data_ptr(), st), "nufft_crop_apod")
+        return out
+
+    def _loss_grad(self, x, y, need_grad, want_total=True):
+        x = self._check(x)
+        B, T, dev = x.shape[0], self.frames, x.device
+        y = y.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if y.dim() != 4 or tuple(y.shape[1:]) != (T, self.J, 2) or y.shape[0] not in (1, B):
+            raise ValueError("measurement shape %s, expected [1 or %d, %d, %d, 2]" % (tuple(y.shape), B, T, self.J))
+        L, plan, st = _lib.lib(), self._plan(dev), _lib.stream_of(x)
+        nblk = L.nufft_interp_blocks(self.J)
+        loss = torch.empty(B, device=dev, dtype=torch.float32)
+        grad = torch.empty_like(x) if need_grad else None
+        t0 = None
+        if self._prof is not None:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(dev))
+        for i in range(0, B, self.max_chunk):
+            xc = x[i:i + self.max_chunk]
+            n = xc.shape[0]
+            Xg = self._grid_fft(xc)
+            res = torch.empty(n, T, self.J, 2, device=dev, dtype=torch.float32)
+            part = torch.empty(n * T * nblk, device=dev, dtype=torch.float32)
+            yc = y if y.shape[0] == 1 else y[i:i + n]
+            rc = L.nufft_interp(Xg.data_ptr(), n * T, T, C.byref(plan), yc.data_ptr(), yc.shape[0], 2.0,
+                                res.data_ptr(), part.data_ptr(), loss[i:i + n].data_ptr(), None, st)
+            _lib.check(rc, "nufft_interp")
+            if need_grad:
+                del Xg
+                grad[i:i + n] = self._type1(res, 1.0)
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream(dev))
+            self._prof.setdefault("nufft_loss_grad", []).append((t0, t1))
+        return loss, (loss.sum() if want_total else None), grad
+
+    # ------------------------------------------------------------------ operator API
+    def __call__(self, x):
+        return _ForwardFn.apply(x, self)
+
+    def loss(self, x, y, unit_upstream=False):
+        return _LossFn.apply(x, self, y, unit_upstream)
+
+    def gradient(self, x, y, return_loss=False):
+        loss, total, grad = self._loss_grad(x, y, True, want_total=return_loss)
+        grad = grad.to(x.dtype)
+        return (grad, total) if return_loss else grad

@@ -1,0 +1,72 @@
+"""The gridding (NUFFT) path for radial sampling against the direct non-uniform DFT in fp64.
+NO REFERENCE COUNTERPART -- parity unpinned; the tolerance is the north_star's 1e-4 relative
+(max-norm), which the Kaiser-Bessel design (width 6, oversampling 2) meets with a margin."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.nufft_oracle import NUDFTOracle
+from tests.helpers import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def make(**kw):
+    from step_amd.forward_operator import get_operator
+    return get_operator("mri_radial", **kw)
+
+
+@pytest.mark.parametrize("spokes,frames,shared", [(32, 12, False), (13, 3, True)])
+def test_matches_direct_nudft(spokes, frames, shared, dev):
+    from step_amd.forward_operator import golden_angle_radial
+    traj = golden_angle_radial(1 if shared else frames, spokes, 192)
+    if shared:                                              # an arbitrary (non-radial) set as well
+        rng = np.random.RandomState(0)
+        traj = np.concatenate([traj, rng.uniform(-96, 96, (1, 500, 2))], axis=1)
+    op, orc = make(spokes=spokes, frames=frames, trajectory=traj), NUDFTOracle(traj, 192)
+    gen = torch.Generator().manual_seed(spokes)
+    x = torch.randn(2, frames, 2, 192, 192, generator=gen)
+    y = orc(torch.randn(2, frames, 2, 192, 192, generator=gen)).float() + 0.1 * torch.randn(2, frames, op.J, 2, generator=gen)
+    assert_close(op(x.to(dev)), orc(x), RTOL, "type 2 (image -> samples)")
+    v = torch.randn(2, frames, op.J, 2, generator=gen)
+    assert_close(op._type1(v.to(dev), 1.0), orc.adjoint(v), RTOL, "type 1 (samples -> image)")
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    assert_close(op.loss(x.to(dev), y.to(dev)), orc.loss(x, y), RTOL, "per-chain loss")
+    assert_close(op.gradient(x.to(dev), y[:1].to(dev))[1], orc.gradient(x[1:], y[:1])[0], RTOL, "broadcast measurement")
+
+
+def test_adjoint_identity_and_autograd(dev):
+    op = make(spokes=32, frames=12)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
+    v = torch.randn(3, 12, op.J, 2, device=dev, generator=gen)
+    lhs = (op(x) * v).flatten(1).sum(-1).double()
+    rhs = (x * op._type1(v, 1.0)).flatten(1).sum(-1).double()
+    assert ((lhs - rhs).abs() / lhs.abs()).max().item() <= 1e-4          # <A x, v> = <x, A^H v>
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
+    g = op.gradient(x, y)
+    xr = x.clone().requires_grad_(True)
+    w = torch.tensor([0.5, -2.0, 1.0], device=dev)
+    ga = torch.autograd.grad((op.loss(xr, y) * w).sum(), xr)[0]
+    assert_close(ga, g * w.view(-1, 1, 1, 1, 1), 1e-5, "autograd through loss")
+    gv = torch.autograd.grad((op(xr) * v).sum(), xr)[0]
+    assert_close(gv, op._type1(v, 1.0), 1e-6, "autograd through A(x)")
+    # deterministic (the spread is a gather) and chunking-invariant
+    assert torch.equal(op.gradient(x, y), g)
+    op.max_chunk = 2
+    assert torch.equal(op.gradient(x, y), g)
+
+
+def test_radial_langevin_step_runs_in_the_sampler(dev):
+    from step_amd.sampler import MCMCSampler
+    op = make(spokes=16, frames=12)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x0 = torch.randn(2, 12, 2, 192, 192, device=dev, generator=gen)
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
+    s = MCMCSampler(num_steps=3, lr=1e-7, tau=1.0, mc_algo="langevin", prior_solver="gaussian")
+    l0 = op.loss(x0, y)
+    out = s.optimize(x0, op, y, 10.0, 0.0)
+    assert torch.isfinite(out).all() and (op.loss(out, y) < l0).all()
