@@ -169,6 +169,28 @@ def dry_run(a, rank, world):
         dist.destroy_process_group()
 
 
+def small_batch_line(op, y, dev, B, steps=2000):
+    """ms per step and chain-steps/s of the black-hole step at a small batch (wall clock over
+    `steps` steps after a warm-up), with the HBM roofline of the step as a whole: the two DFT
+    kernels stream 2 x 4*T*H*W bytes per chain and the closure stage rides in them."""
+    g = torch.Generator(device=dev).manual_seed(1000 + B)
+    x = torch.rand(B, 64, 1, 256, 256, device=dev, generator=g) * 2 - 1
+    for _ in range(300):
+        op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    byts = 2 * 4.0 * 64 * 65536 * B
+    gbs = byts / (ms * 1e-3) / 1e9
+    return dict(ms_per_step=ms, value=B / ms * 1e3, unit="chain-steps/s",
+                launches_per_step=2 if op._fused_ok(y, B) else 3,
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              algorithmic="whole step: 2 x 4*T*H*W bytes per chain x %d chains / ms_per_step" % B))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -328,6 +350,10 @@ def main():
             out["config"]["reference_counterpart"] = False
         out["derived"] = dict(samples_per_hour_operator_only=3600.0 * out["value"] / per_sample,
                               langevin_steps_per_sample=per_sample)
+        if a.task == "blackhole" and a.batch is None and not a.no_small_batches and op.path == "sep3":
+            # the batches a GPU really sees: the reference runs B = 1 (sample.py:64-65) and config 4
+            # on 8 GPUs is 64 / 8 = 8 chains per GPU.  Same operator, same step, own roofline.
+            out["small_batches"] = {"B%d" % b: small_batch_line(op, y, dev, b) for b in (8, 1)}
         if world == 1 and not a.no_cpu_baseline:
             if a.task == "blackhole":
                 out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)
