@@ -1,7 +1,7 @@
 """MRI step timing at B = 32, 64, 256 (median of 20 event-timed launches).
 usage: python scripts/kbench_mri.py [lib.so] [variant]     (variant 1 pins the first-generation kernel)"""
 import sys, os, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1:
     os.environ['STEP_AMD_LIB'] = os.path.abspath(sys.argv[1])
 from step_amd.forward_operator import get_operator
