@@ -224,14 +224,31 @@ typedef struct {               /* device workspace of the fused step (caller-own
     float* S;                  /* [B][T][4], 16-byte aligned */
 } bh_step_ws_t;
 
+typedef struct {               /* MCMCSampler.optimize's update fused into the adjoint (daps.py:210-223) */
+    float* x_inout;            /* the state: must be the `x` the step was evaluated at; updated in place */
+    const float* x0hat;
+    float lr, inv_sigma2;      /* x -= lr * (g + (x - x0hat) * inv_sigma2), g = d loss / d x */
+} bh_update_t;
+
 /* loss [B], chi2 [B][5] (may be NULL), loss_total (may be NULL) = sum of loss[],
  * grad [B][T][H*W] = out_scale * chain_scale[b] * d loss[b] / d x' with x' = 0.5 x + 0.5
- * (out_scale = 0.5 gives d loss / d x; chain_scale may be NULL). */
+ * (out_scale = 0.5 gives d loss / d x; chain_scale may be NULL).
+ * Exactly one of `grad` and `update` is non-NULL: with `update` the gradient is not written
+ * anywhere -- the adjoint applies the gradient-descent step to x where it would have stored it. */
 int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri, int T, int F,
                       int H, int W, const float* x, int B, const bh_tables_t* tab,
                       const int32_t* frame_tab, const bh_meas_t* y, const bh_weights_t* w,
                       const bh_step_ws_t* ws, const float* chain_scale, float out_scale,
-                      float* loss, float* chi2, float* loss_total, float* grad, void* stream);
+                      float* loss, float* chi2, float* loss_total, float* grad,
+                      const bh_update_t* update, void* stream);
+
+/* The three-kernel path's adjoint with the same fused update (see bh_update_t): replaces
+ * bh_dft_adj_sep3 + mcmc_update(algo 2). */
+int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
+                           const float* gvis_c64, const float* gflux, const float* chain_scale,
+                           int B, float out_scale, float* x, const float* x0hat, float lr,
+                           float inv_sigma2, const float* sum_in, int sum_n, float* sum_out,
+                           void* stream);
 
 /* ------------------------------------------------------------------ dynamic MRI
  * x, y, out: [B][T][2][R][R] fp32 (channel 0 = Re, 1 = Im); R == 192.

@@ -16,6 +16,7 @@ p.add_argument('--batch', type=int, default=64)
 p.add_argument('--steps', type=int, default=60)
 p.add_argument('--reps', type=int, default=5)
 p.add_argument('--latent', action='store_true')
+p.add_argument('--optimize', action='store_true', help='MCMCSampler.optimize (the pixel-space branch of LatentDAPS, daps.py:312)')
 p.add_argument('--noise', default='torch', choices=['torch', 'philox'])
 a = p.parse_args()
 dev = torch.device('cuda:0')
@@ -49,14 +50,15 @@ else:
     model, target, shape = None, op, (a.batch, 64, 1, 256, 256)
 x0 = torch.rand(*shape, device=dev, generator=g) * 2 - 1
 xt = x0 + 0.1 * torch.randn(*shape, device=dev, generator=g)
-mc.sample(xt, model, x0, target, y, 0.5, 0.0)           # warm-up
+run = (lambda: mc.optimize(x0, target, y, 0.5, 0.0)) if a.optimize else (lambda: mc.sample(xt, model, x0, target, y, 0.5, 0.0))
+run()           # warm-up
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.reps):
-    out = mc.sample(xt, model, x0, target, y, 0.5, 0.0)
+    out = run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 assert torch.isfinite(out).all()
-print('noise=%s ' % a.noise + '%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
+print(('optimize ' if a.optimize else 'noise=%s ' % a.noise) + '%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
       % ('latent+stand-in decoder' if a.latent else 'pixel space', a.batch, a.steps, 1e3 * dt / a.steps,
          a.batch * a.steps / dt, 25 * dt * 60 / a.steps, 3600 * a.batch / (25 * dt * 60 / a.steps)))

@@ -169,6 +169,16 @@ struct S3FusedAdj {
     float* total;             // sum of loss[] or null
 };
 
+// UPD instantiations of the adjoint: the gradient is not stored; the gradient-descent update of
+// MCMCSampler.optimize (daps.py:210-223), x -= lr (g + (x - x0hat) / sigma^2), is applied where
+// the tile would have been written: x and x0hat are read, x is written, and the gradient never
+// reaches HBM (one 1 GB write and one 1 GB read less per step at 64 chains).
+struct S3Update {
+    float* x;                 // [B][T][H*W] state, updated in place
+    const float* x0;          // x0hat
+    float lr, inv_sigma2;
+};
+
 // chi^2 sums of one chain -> loss and the backward factors (same order of operations as
 // k_closure_loss).  s_* are the sums over all frames.
 __device__ __forceinline__ void s3_chain_factors(const S3FusedAdj& z, int T, float s_cp, float s_ca,
@@ -451,13 +461,13 @@ extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int
 // [(((part*2 + kb)*3 + plane)*2 + h)][H/2 rows y]; part 0 = Re ey (with the flux row f = F,
 // ey = 1), part 1 = Im ey; kb = block of 16 baselines.  B operand per chain in registers:
 // wR[f][x] = Re(conj(ex) g) = exR gR + exI gI,  wI[f][x] = Im(conj(ex) g) = exR gI - exI gR.
-template <int H, int W, bool FUSED>
+template <int H, int W, bool FUSED, bool UPD>
 __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
     const float* __restrict__ chain_scale, float* __restrict__ grad, int T, int F, int B, int cpw,
     float out_scale, const float* __restrict__ sum_in, int sum_n, float* __restrict__ sum_out,
-    S3FusedAdj fz) {
+    S3FusedAdj fz, S3Update up) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
     constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
     // optional rider: sum_out = sum(sum_in[0 .. sum_n)) in a fixed order (the scalar loss that
@@ -636,9 +646,12 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                 split3(wr, rh[kb], rm[kb], rl[kb]);
                 split3(wi, ih[kb], im[kb], il[kb]);
             }
-            float* gf = grad + ((size_t)b * T + t) * H * W + xcol;
+            const size_t fo = ((size_t)b * T + t) * H * W + xcol;
+            float* gf = (UPD ? up.x : grad) + fo;
+            const float* x0f = UPD ? up.x0 + fo : nullptr;
 #pragma unroll 1
             for (int tile = 0; tile < NTILE; ++tile) {
+
                 f32x16 ev, od;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ev[r] = od[r] = 0.f;
@@ -656,11 +669,37 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                         }
                     }
                 const int ytop = tile * 32 + 4 * h;
+                if (UPD) {
+                    // state and x0hat behind the matrix work, upper rows then mirror rows: 32 values
+                    // in flight per lane next to the accumulators is what the register file takes;
+                    // the other seven waves of the workgroup cover a wave's wait
+                    float xo[16], xh[16], xb[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xo[r] = gf[(ytop + (r & 3) + 8 * (r >> 2)) * W];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xh[r] = x0f[(ytop + (r & 3) + 8 * (r >> 2)) * W];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int y = ytop + (r & 3) + 8 * (r >> 2);
+                        S3_STG(gf + y * W, xo[r] - up.lr * ((ev[r] + od[r]) + (xo[r] - xh[r]) * up.inv_sigma2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xb[r] = gf[(H - 1 - (ytop + (r & 3) + 8 * (r >> 2))) * W];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xh[r] = x0f[(H - 1 - (ytop + (r & 3) + 8 * (r >> 2))) * W];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int y = H - 1 - (ytop + (r & 3) + 8 * (r >> 2));
+                        S3_STG(gf + y * W, xb[r] - up.lr * ((ev[r] - od[r]) + (xb[r] - xh[r]) * up.inv_sigma2));
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int y = ytop + (r & 3) + 8 * (r >> 2);
                     S3_STG(gf + y * W, ev[r] + od[r]);
                     S3_STG(gf + (H - 1 - y) * W, ev[r] - od[r]);
+                }
                 }
             }
         }
@@ -706,30 +745,30 @@ template <int H, int W>
 static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, const float* gvis,
                           const float* gflux, const float* chain_scale, int B, float out_scale,
                           float* grad, const float* sum_in, int sum_n, float* sum_out,
-                          const S3FusedAdj* fz, hipStream_t st) {
+                          const S3FusedAdj* fz, const S3Update* up, hipStream_t st) {
     int cpw, gx;
     s3_grid(B, T, &cpw, &gx);
     const size_t lds = (size_t)24 * (H / 2) * 16 + (size_t)S3_GCH * S3_GROW * 4 + (2 * S3_GCH + 8) * 4 +
                        (68 + 192 + 256) * 4;
-    if (fz) {
-        step_allow_lds((const void*)k_dft_adj_s3<H, W, true>, lds);
-        hipLaunchKernelGGL((k_dft_adj_s3<H, W, true>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
-                           gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out, *fz);
-    } else {
-        step_allow_lds((const void*)k_dft_adj_s3<H, W, false>, lds);
-        hipLaunchKernelGGL((k_dft_adj_s3<H, W, false>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri,
-                           gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,
-                           S3FusedAdj{});
-    }
+#define S3_ADJ_LAUNCH(FU, UP)                                                                              \
+    step_allow_lds((const void*)k_dft_adj_s3<H, W, FU, UP>, lds);                                          \
+    hipLaunchKernelGGL((k_dft_adj_s3<H, W, FU, UP>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri, \
+                       gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,    \
+                       fz ? *fz : S3FusedAdj{}, up ? *up : S3Update{})
+    if (fz && up) { S3_ADJ_LAUNCH(true, true); }
+    else if (fz) { S3_ADJ_LAUNCH(true, false); }
+    else if (up) { S3_ADJ_LAUNCH(false, true); }
+    else { S3_ADJ_LAUNCH(false, false); }
+#undef S3_ADJ_LAUNCH
 }
 
 static void dispatch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, int H, const float* gvis,
                             const float* gflux, const float* chain_scale, int B, float out_scale,
                             float* grad, const float* sum_in, int sum_n, float* sum_out,
-                            const S3FusedAdj* fz, hipStream_t st) {
-    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
-    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
-    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, st);
+                            const S3FusedAdj* fz, const S3Update* up, hipStream_t st) {
+    if (H == 256) launch_adj_s3<256, 256>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, up, st);
+    else if (H == 128) launch_adj_s3<128, 128>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, up, st);
+    else launch_adj_s3<64, 64>(ey_ri, ex_ri, T, F, gvis, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n, sum_out, fz, up, st);
 }
 
 extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
@@ -742,8 +781,28 @@ extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, in
                  "bh_dft_adj_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
     dispatch_adj_s3(ey_ri, ex_ri, T, F, H, gvis_c64, gflux, chain_scale, B, out_scale, grad, sum_in, sum_n,
-                    sum_out, nullptr, (hipStream_t)stream);
+                    sum_out, nullptr, nullptr, (hipStream_t)stream);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3");
+    return STEP_OK;
+}
+
+// bh_dft_adj_sep3 with MCMCSampler.optimize's update (daps.py:210-223) in place of the gradient
+// store: x[b][t][n] -= lr * (g + (x - x0hat) * inv_sigma2) with g = the gradient bh_dft_adj_sep3
+// would have written.
+extern "C" int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
+                                      const float* gvis_c64, const float* gflux, const float* chain_scale,
+                                      int B, float out_scale, float* x, const float* x0hat, float lr,
+                                      float inv_sigma2, const float* sum_in, int sum_n, float* sum_out,
+                                      void* stream) {
+    STEP_REQUIRE(ey_ri && ex_ri && gvis_c64 && gflux && x && x0hat, "bh_dft_adj_sep3_update: null pointer");
+    STEP_REQUIRE(!sum_out || (sum_in && sum_n > 0), "bh_dft_adj_sep3_update: sum_out needs sum_in and sum_n > 0");
+    STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
+                 "bh_dft_adj_sep3_update: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
+    STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3_update: image %dx%d not built (256, 128, 64 square)", H, W);
+    S3Update up{x, x0hat, lr, inv_sigma2};
+    dispatch_adj_s3(ey_ri, ex_ri, T, F, H, gvis_c64, gflux, chain_scale, B, out_scale, nullptr, sum_in, sum_n,
+                    sum_out, nullptr, &up, (hipStream_t)stream);
+    STEP_CHECK_LAUNCH("bh_dft_adj_sep3_update");
     return STEP_OK;
 }
 
@@ -752,9 +811,12 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
                                  int H, int W, const float* x, int B, const bh_tables_t* tab,
                                  const int32_t* frame_tab, const bh_meas_t* y, const bh_weights_t* w,
                                  const bh_step_ws_t* ws, const float* chain_scale, float out_scale,
-                                 float* loss, float* chi2, float* loss_total, float* grad, void* stream) {
-    STEP_REQUIRE(ey_t && ey_ri && ex_ri && x && tab && frame_tab && y && w && ws && loss && grad,
+                                 float* loss, float* chi2, float* loss_total, float* grad,
+                                 const bh_update_t* update, void* stream) {
+    STEP_REQUIRE(ey_t && ey_ri && ex_ri && x && tab && frame_tab && y && w && ws && loss,
                  "bh_loss_grad_sep3: null pointer");
+    STEP_REQUIRE((grad != nullptr) != (update != nullptr), "bh_loss_grad_sep3: pass either grad or update");
+    STEP_REQUIRE(!update || (update->x0hat && update->x_inout == x), "bh_loss_grad_sep3: update->x_inout must be x, x0hat non-null");
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_loss_grad_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_loss_grad_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
@@ -778,8 +840,10 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
     S3FusedAdj fa{(const float2*)ws->vis_c64, ws->flux, ws->S, ws->dcp, ws->dca, tab->cp_ptr, tab->cp_ent,
                   tab->ca_ptr, tab->ca_ent, y->flux, w->w_cp, w->w_camp, w->w_flux, w->normalize,
                   tab->n_tri, tab->n_quad, loss, chi2, loss_total};
+    S3Update up{};
+    if (update) up = S3Update{update->x_inout, update->x0hat, update->lr, update->inv_sigma2};
     dispatch_adj_s3(ey_ri, ex_ri, T, F, H, nullptr, nullptr, chain_scale, B, out_scale, grad, nullptr, 0,
-                    nullptr, &fa, st);
+                    nullptr, &fa, update ? &up : nullptr, st);
     STEP_CHECK_LAUNCH("bh_loss_grad_sep3 (adjoint)");
     return STEP_OK;
 }

@@ -476,16 +476,31 @@ class BlackHoleImagingTorch(Operator):
         _lib.check(rc, "bh_dft_fwd_" + self.path)
         return torch.view_as_complex(vis), flux
 
-    def _adjoint(self, gvis, gflux, chain_scale, out_scale, sum_of=None):
+    def _adjoint(self, gvis, gflux, chain_scale, out_scale, sum_of=None, update=None):
         """gvis [B, T*F, 2] fp32, gflux [B, T] -> grad [B, T, H*W] fp32.
         sum_of: a 1-d fp32 tensor whose sum the caller also wants (-> (grad, 0-d sum));
-        on the sep3 path it rides along in the adjoint launch."""
+        on the sep3 path it rides along in the adjoint launch.
+        update = (x [B, T, H*W], x0hat, lr, inv_sigma2) (sep3 only): no gradient is written, the
+        adjoint applies x -= lr (g + (x - x0hat) inv_sigma2) in place and grad comes back None."""
         B = gvis.shape[0]
-        grad = torch.empty(B, self.T, self.H * self.W, device=self.device, dtype=torch.float32)
-        L, st = _lib.lib(), _lib.stream_of(grad)
+        L, st = _lib.lib(), _lib.stream_of(gvis)
         cs = None if chain_scale is None else chain_scale.data_ptr()
-        t0 = self._tick()
         total = None
+        if update is not None:
+            xv, x0, lr, inv_sigma2 = update
+            if sum_of is not None:
+                total = torch.empty(1, device=self.device, dtype=torch.float32)
+            t0 = self._tick()
+            rc = L.bh_dft_adj_sep3_update(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
+                                          self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
+                                          out_scale, xv.data_ptr(), x0.data_ptr(), lr, inv_sigma2,
+                                          _lib.ptr(sum_of), 0 if sum_of is None else sum_of.numel(),
+                                          _lib.ptr(total), st)
+            self._tock("dft_adj", t0)
+            _lib.check(rc, "bh_dft_adj_sep3_update")
+            return None, (total[0] if total is not None else None)
+        grad = torch.empty(B, self.T, self.H * self.W, device=self.device, dtype=torch.float32)
+        t0 = self._tick()
         if self.path == "sep3":
             if sum_of is not None:
                 total = torch.empty(1, device=self.device, dtype=torch.float32)
@@ -571,9 +586,11 @@ class BlackHoleImagingTorch(Operator):
                 and (self.weight_cp == 0 or (y.cphase is not None and y.cphase.shape[0] == 1))
                 and (self.weight_camp == 0 or (y.logcamp is not None and y.logcamp.shape[0] == 1)))
 
-    def _fused_step(self, x, y, want_total=True, chain_scale=None):
+    def _fused_step(self, x, y, want_total=True, chain_scale=None, update=None):
         """The whole data step in two launches (bh_loss_grad_sep3): -> loss [B], total (0-d) or
-        None, grad [B, T, H*W] = d loss / d x."""
+        None, grad [B, T, H*W] = d loss / d x.  update = (x0hat [B, T, H*W], lr, inv_sigma2): no
+        gradient is written (grad comes back None); the adjoint applies the descent step to x,
+        which must then be the caller's own contiguous fp32 storage."""
         xv = self._video(x)
         B, M, T, dev = xv.shape[0], self.T * self.F, self.T, self.device
         Kcp, Kca = self.cphase_dim, self.logcamp_dim
@@ -581,7 +598,13 @@ class BlackHoleImagingTorch(Operator):
         sizes = (4 * B * T, 2 * B * M, B * T, B * Kcp, B * Kca, B, 5 * B, 4)
         buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         S, vis, flux, dcp, dca, loss, chi2, total = torch.split(buf, sizes)
-        grad = torch.empty(B, T, self.H * self.W, device=dev, dtype=torch.float32)
+        grad = upd = None
+        if update is None:
+            grad = torch.empty(B, T, self.H * self.W, device=dev, dtype=torch.float32)
+        else:
+            if xv.data_ptr() != x.data_ptr():
+                raise ValueError("in-place update needs a contiguous fp32 state on the operator's device")
+            upd = _lib.bh_update_t(xv.data_ptr(), update[0].data_ptr(), update[1], update[2])
         ws = _lib.bh_step_ws_t(vis.data_ptr(), flux.data_ptr(), dcp.data_ptr(), dca.data_ptr(), S.data_ptr())
         meas, keep = self._meas(y)
         t0 = self._tick()
@@ -589,8 +612,8 @@ class BlackHoleImagingTorch(Operator):
             self._ey_t.data_ptr(), self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), T, self.F, self.H,
             self.W, xv.data_ptr(), B, C.byref(self._tab), self._frame_tab.data_ptr(), C.byref(meas),
             C.byref(self._weights), C.byref(ws), _lib.ptr(chain_scale), 0.5, loss.data_ptr(),
-            chi2.data_ptr(), total.data_ptr() if want_total else None, grad.data_ptr(),
-            _lib.stream_of(xv))
+            chi2.data_ptr(), total.data_ptr() if want_total else None, _lib.ptr(grad),
+            None if upd is None else C.byref(upd), _lib.stream_of(xv))
         self._tock("fused_step", t0)
         _lib.check(rc, "bh_loss_grad_sep3")
         self.last_chi2 = chi2.view(B, 5)
@@ -802,6 +825,38 @@ class BlackHoleImagingTorch(Operator):
             grad, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss)
             return grad.view(x.shape).to(x.dtype), total
         return self._adjoint(gvis, gflux, None, 0.5).view(x.shape).to(x.dtype)
+
+    @property
+    def has_descent_step(self):
+        """descent_step lives in the folded 3xbf16 adjoint: the default path only."""
+        return self.path == "sep3"
+
+    def descent_step(self, x, y, x0hat, lr, inv_sigma2, return_loss=False):
+        """One step of MCMCSampler.optimize (daps.py:210-223) in place on x:
+        ``x -= lr * (gradient(x, y) + (x - x0hat) * inv_sigma2)`` with the update applied by the
+        adjoint kernel where it would have stored the gradient, which therefore never reaches HBM
+        (per step and chain 4 video-sized streams instead of 6 + 2).  x: contiguous fp32 on the
+        operator's device, modified; -> the summed loss at the old x (0-d) or None."""
+        if self.path != "sep3":
+            raise NotImplementedError("descent_step is built on the sep3 kernels only")
+        if (x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != self.device.type
+                or (self.device.index is not None and x.device.index != self.device.index)
+                or x.requires_grad):
+            raise ValueError("descent_step needs a contiguous fp32 state on %s without autograd history" % self.device)
+        x0 = x0hat.detach()
+        if x0.dtype != torch.float32 or not x0.is_contiguous() or x0.shape != x.shape or x0.device != x.device:
+            x0 = x0.to(device=x.device, dtype=torch.float32).expand_as(x).contiguous()
+        if x0.data_ptr() == x.data_ptr():
+            raise ValueError("descent_step: x and x0hat must not share storage")
+        lr, inv_sigma2 = float(lr), float(inv_sigma2)
+        if self._fused_ok(y, x.shape[0]):
+            _, total, _ = self._fused_step(x, y, want_total=return_loss, update=(x0, lr, inv_sigma2))
+            return total
+        loss, gvis, gflux = self._loss_forward(x, y, True)
+        xv = x.view(-1, self.T, self.H * self.W)
+        _, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss if return_loss else None,
+                                 update=(xv, x0, lr, inv_sigma2))
+        return total
 
 
 def thermal_measure(op, x, generator=None):

@@ -106,6 +106,7 @@ class MCMCSampler(nn.Module):
         self.chain_generators = None     # list of torch.Generator, one per chain, or None
         self.chain_seeds = None          # int64 [B] on the device ('philox'), or None
         self.noise_step = 0              # Philox counter: steps taken since set_chains
+        self.fuse_descent = True         # optimize(): use operator.descent_step where offered
 
     def set_chains(self, generators=None, seeds=None):
         """Per-chain randomness for the next sample() calls: torch generators (start velocity,
@@ -265,8 +266,10 @@ class MCMCSampler(nn.Module):
         return x.detach()
 
     def optimize(self, x0hat, operator, measurement, sigma, ratio, record=False, verbose=False):
-        """Pixel-space gradient descent on decoded frames (daps.py:210-223); the update
-        ``x -= lr (g + (x - x0hat) / sigma^2)`` is one fused kernel on the GPU."""
+        """Pixel-space gradient descent on decoded frames (daps.py:210-223).  An operator that
+        offers ``descent_step`` (the black-hole operator) applies the update
+        ``x -= lr (g + (x - x0hat) / sigma^2)`` inside its adjoint kernel, so the gradient never
+        reaches HBM; otherwise the update is one fused kernel after ``operator.gradient``."""
         lr = self.get_lr(ratio)
         x = x0hat.clone().detach()
         fused = x.device.type == 'cuda' and x.dtype == torch.float32
@@ -274,6 +277,10 @@ class MCMCSampler(nn.Module):
             x = x.contiguous()
             x0 = self._kernel_tensor(x0hat.detach(), x)
             params = _lib.mcmc_params_t(1.0, 1.0 / float(sigma) ** 2, lr, 0.0, 0.0, 0.0, 0.0, 2)
+            if not record and self.fuse_descent and getattr(operator, 'has_descent_step', False):
+                for _ in range(self.num_steps):
+                    operator.descent_step(x, measurement, x0, lr, 1.0 / float(sigma) ** 2)
+                return x.detach()
         for _ in range(self.num_steps):
             g, loss = operator.gradient(x, measurement, return_loss=True)
             if fused:

@@ -89,3 +89,51 @@ def test_fallbacks(dev):
     rc = _lib.lib().bh_build_frame_closures(_lib.ptr(cpi), _lib.ptr(cpc), cpi.shape[0], _lib.ptr(cai),
                                             cai.shape[0], 64, op.F, _lib.ptr(ft))
     assert rc == -1 and b"spans frames" in _lib.lib().step_last_error()
+
+
+@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 33)])
+def test_descent_step_equals_gradient_then_update(n_sites, imsize, B, dev):
+    """descent_step (the update of MCMCSampler.optimize, daps.py:210-223, applied inside the
+    adjoint) == gradient() followed by the same arithmetic in torch, on the two-launch path
+    (B <= 31) and on the three-kernel path."""
+    op = make(dev, n_sites, imsize)
+    gen = torch.Generator(device=dev).manual_seed(100 + B)
+    x = torch.rand(B, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1
+    x0 = x + 0.05 * torch.randn(x.shape, device=dev, generator=gen)
+    y = op(torch.rand(1, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1)
+    g, total = op.gradient(x, y, return_loss=True)
+    # a step size that makes the data term and the prior term comparable in the update
+    lr = float(0.02 / g.abs().max())
+    inv_s2 = float(0.3 * g.abs().max())
+    fp = lambda z: z.double()
+    want = (fp(x) - lr * (fp(g) + (fp(x) - fp(x0)) * inv_s2)).float()
+    xs = x.clone()
+    got_total = op.descent_step(xs, y, x0, lr, inv_s2, return_loss=True)
+    assert_close(got_total, total, 1e-6, "loss at the old x")
+    # the update relative to the step it takes (x itself is O(1), the step O(0.02))
+    assert_close(xs - x, want - x, 2e-5, "update")
+    assert (xs - want).abs().max().item() <= 4e-7
+    # x0hat given as a broadcastable / non-contiguous tensor
+    xs2 = x.clone()
+    op.descent_step(xs2, y, x0.transpose(3, 4).contiguous().transpose(3, 4), lr, inv_s2)
+    assert torch.equal(xs2, xs)
+    with pytest.raises(ValueError):
+        op.descent_step(xs2, y, xs2, lr, inv_s2)
+    with pytest.raises(ValueError):
+        op.descent_step(xs2.transpose(3, 4), y, x0, lr, inv_s2)
+
+
+def test_optimize_with_and_without_the_fused_descent(dev):
+    """MCMCSampler.optimize through descent_step == through gradient + mcmc_update."""
+    from step_amd.sampler.daps import MCMCSampler
+    op = make(dev, 6, 64)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x0 = torch.rand(4, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1
+    y = op(torch.rand(1, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1)
+    g = op.gradient(x0, y)
+    mc = MCMCSampler(num_steps=6, lr=float(0.01 / g.abs().max()), tau=0.01)
+    a = mc.optimize(x0, op, y, 0.7, 0.2)
+    mc.fuse_descent = False
+    b = mc.optimize(x0, op, y, 0.7, 0.2)
+    assert not torch.equal(a, x0)
+    assert_close(a - x0, b - x0, 1e-4, "six descent steps")
