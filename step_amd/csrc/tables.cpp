@@ -22,7 +22,7 @@ void step_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* step_last_error(void) { return g_err; }
-extern "C" int step_abi_version(void) { return 3; }   // 3: mri_loss_grad takes `variant`, bh_weights_t has `cphase_form`
+extern "C" int step_abi_version(void) { return 4; }   // 4: bh_loss_grad_sep3 takes `update`
 
 #define REQ(cond, ...)                      \
     do {                                    \
