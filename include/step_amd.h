@@ -272,7 +272,9 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
  * rows' sum |y|^2 of a batch-1 measurement); loss [B]; loss_total (may be NULL): sum of loss[].
  * variant: 0 = choose by mask (the software-pipelined kernel when every mask frame keeps <= 64
  * rows, i.e. every shipped mode), 1 = first-generation kernel (any mask; cross-checks),
- * 2 = pipelined kernel (STEP_E_INVALID if a mask frame keeps more than 64 rows). */
+ * 2 = pipelined kernel (STEP_E_INVALID if a mask frame keeps more than 64 rows),
+ * 3 = in-register column transforms with two workgroups per CU (<= 52 kept rows per frame; same
+ * results to rounding; measured slower than 2 so far and never chosen by 0). */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
                   const float* chain_scale, int variant, float* loss_part, float* loss,
