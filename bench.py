@@ -77,17 +77,24 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+TRAFFIC_SOURCE = [None]
+
+
 def measured_traffic(kernel, matches):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
     (newest profiles/r*_traffic.json that has the kernel; FETCH_SIZE/WRITE_SIZE cannot be collected from inside this
-    process).  Only returned when the profiled configuration is the one being run."""
+    process).  Only returned when the profiled configuration is the one being run; the file it
+    came from is reported next to it (`traffic_source`), so that a number measured on an older
+    kernel is recognisable as such."""
     if not matches:
         return None
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
             with open(path) as fh:
-                return json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"]
+                v = json.load(fh)["kernels"][kernel]["hbm_bytes_per_launch"]
+            TRAFFIC_SOURCE[0] = "profiles/" + os.path.basename(path) + " (committed rocprofv3 --pmc passes, not this run)"
+            return v
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -244,6 +251,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # the first collectives of a process set RCCL up (communicator, kernels: hundreds of ms with the
+    # GPU idle): here, ahead of the pre-warm, so that the barrier that opens the timed region takes
+    # its 25 us and the clocks stay where the warm-up left them
+    for _ in range(3):
+        barrier()
     # untimed, disclosed pre-warm: leave the clock ramp of an idle GPU before anything is timed
     t_pre = time.perf_counter()
     prewarm_steps = 0
@@ -343,6 +355,8 @@ def main():
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)
+        if roof.get("traffic") is not None:
+            roof["traffic_source"] = TRAFFIC_SOURCE[0]
         # BASELINE.json's second metric, derived: Langevin steps per posterior sample at the shipped
         # configs; operator work only, the prior network is not in this bench
         per_sample = 1500 if a.task == "blackhole" else 1060

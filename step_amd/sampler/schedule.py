@@ -14,7 +14,8 @@ class EDMScheduler:
 
     def __init__(self, num_steps, sigma_max=100, sigma_min=1e-2, timestep='poly-7'):
         self.num_steps = num_steps + 1                      # include the initial step
-        sigma_max, sigma_min = float(sigma_max), float(sigma_min)
+        # sigma_max is used as given: LatentDAPS passes a float32 0-d tensor per annealing step
+        # (daps.py:301), and the reference's grid is then float32 tensor arithmetic, not float64
         self.sigma_max, self.sigma_min = sigma_max, sigma_min
         p = int(timestep.split('-')[1])
         self._fn = lambda r: (sigma_max ** (1 / p) + r * (sigma_min ** (1 / p) - sigma_max ** (1 / p))) ** p
@@ -23,7 +24,7 @@ class EDMScheduler:
         self.sigma_steps = torch.cat([s, torch.zeros_like(s[:1])])   # last entry forced to 0
 
     def get_discrete_time_steps(self, num_steps):
-        return torch.from_numpy(np.array([self._fn(s) for s in np.linspace(0, 1, num_steps)]))
+        return torch.from_numpy(np.array([self._fn(s) for s in np.linspace(0, 1, num_steps)]))     # scheduler.py:312-315
 
 
 def get_diffusion_scheduler(name: str, **kwargs):
