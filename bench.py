@@ -364,7 +364,7 @@ def main():
             out["config"]["reference_counterpart"] = False
         out["derived"] = dict(samples_per_hour_operator_only=3600.0 * out["value"] / per_sample,
                               langevin_steps_per_sample=per_sample)
-        if a.task == "blackhole" and a.batch is None and not a.no_small_batches and op.path == "sep3":
+        if world == 1 and a.task == "blackhole" and a.batch is None and not a.no_small_batches and op.path == "sep3":
             # the batches a GPU really sees: the reference runs B = 1 (sample.py:64-65) and config 4
             # on 8 GPUs is 64 / 8 = 8 chains per GPU.  Same operator, same step, own roofline.
             out["small_batches"] = {"B%d" % b: small_batch_line(op, y, dev, b) for b in (8, 1)}
