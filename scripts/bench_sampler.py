@@ -18,6 +18,7 @@ p.add_argument('--reps', type=int, default=5)
 p.add_argument('--latent', action='store_true')
 p.add_argument('--optimize', action='store_true', help='MCMCSampler.optimize (the pixel-space branch of LatentDAPS, daps.py:312)')
 p.add_argument('--noise', default='torch', choices=['torch', 'philox'])
+p.add_argument('--graph', action='store_true', help='MCMCSampler(graph=True): the loop as replays of one captured step (philox noise)')
 a = p.parse_args()
 dev = torch.device('cuda:0')
 tab = eht_lite.synthetic_table(8, 64, seed=37, sigma_scale=7e-3)
@@ -40,7 +41,7 @@ class StandIn(torch.nn.Module):
 
 
 mc = MCMCSampler(num_steps=a.steps, lr=1.2e-5, tau=0.021, lr_min_ratio=0.015, prior_solver='gaussian',
-                 mc_algo='hmc', momentum=0.0, noise=a.noise)
+                 mc_algo='hmc', momentum=0.0, noise=a.noise, graph=a.graph)
 if a.noise == 'philox':
     mc.set_chains(seeds=torch.arange(37, 37 + a.batch, dtype=torch.int64, device=dev))
 if a.latent:
@@ -50,6 +51,11 @@ else:
     model, target, shape = None, op, (a.batch, 64, 1, 256, 256)
 x0 = torch.rand(*shape, device=dev, generator=g) * 2 - 1
 xt = x0 + 0.1 * torch.randn(*shape, device=dev, generator=g)
+# a step size at which the chain stays finite on this random start (the shipped lr belongs to the
+# shipped prior's samples; a diverged chain would time the NaN guard, not the loop)
+g0 = target.gradient(x0, y)
+mc.lr = float(1e-3 * mc.tau ** 2 / g0.abs().max())
+del g0
 run = (lambda: mc.optimize(x0, target, y, 0.5, 0.0)) if a.optimize else (lambda: mc.sample(xt, model, x0, target, y, 0.5, 0.0))
 run()           # warm-up
 torch.cuda.synchronize()
@@ -58,7 +64,7 @@ for _ in range(a.reps):
     out = run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
-assert torch.isfinite(out).all()
-print(('optimize ' if a.optimize else 'noise=%s ' % a.noise) + '%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
+assert torch.isfinite(out).all() and (out != 0).any(), 'the chain diverged (NaN guard returned zeros)'
+print(('optimize ' if a.optimize else 'noise=%s%s ' % (a.noise, ' graph' if a.graph else '')) + '%s chains=%d steps=%d: %.2f ms per MCMC step, %.0f chain-steps/s; a 25 x 60-step sample: %.2f s -> %.0f samples/hour/GPU (data-consistency loop only)'
       % ('latent+stand-in decoder' if a.latent else 'pixel space', a.batch, a.steps, 1e3 * dt / a.steps,
          a.batch * a.steps / dt, 25 * dt * 60 / a.steps, 3600 * a.batch / (25 * dt * 60 / a.steps)))

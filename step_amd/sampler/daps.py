@@ -83,11 +83,18 @@ class MCMCSampler(nn.Module):
     ``noise``: 'torch' (default) draws epsilon with torch.randn_like as the reference does
     (daps.py:192), or chain by chain from ``set_chains(generators=...)``; 'philox' draws it inside
     the update kernel from per-chain seeds (``set_chains(seeds=...)``): no noise tensor in HBM,
-    per-chain reproducible, statistical parity only."""
+    per-chain reproducible, statistical parity only.
+
+    ``graph``: with ``noise='philox'``, a prior score that is constant over the inner loop (every
+    solver but 'exact') and an operator that is called directly (pixel-space state), the first step
+    runs eagerly, the step is then captured into a HIP graph -- operator step, update kernel with
+    the step number read from a device word, the increment of that word -- and the rest of the loop
+    is ``num_steps - 1`` replays: no Python, no allocator and no launch set-up per step.  Same kernels,
+    same arguments, bit-identical result (tests/test_gpu_mcmc.py).  Off by default."""
 
     def __init__(self, num_steps, lr, tau=0.01, lr_min_ratio=0.01, prior_solver='gaussian',
                  prior_sigma_min=1e-2, mc_algo='langevin', momentum=0.9, nan_check='deferred',
-                 nan_guard='batch', noise='torch'):
+                 nan_guard='batch', noise='torch', graph=False):
         super().__init__()
         self.num_steps = num_steps
         self.lr = lr
@@ -103,6 +110,7 @@ class MCMCSampler(nn.Module):
         self.nan_guard = nan_guard
         assert noise in ('torch', 'philox')
         self.noise = noise
+        self.graph = bool(graph)
         self.chain_generators = None     # list of torch.Generator, one per chain, or None
         self.chain_seeds = None          # int64 [B] on the device ('philox'), or None
         self.noise_step = 0              # Philox counter: steps taken since set_chains
@@ -222,6 +230,13 @@ class MCMCSampler(nn.Module):
                 raise ValueError("noise='philox' needs set_chains(seeds=int64[%d])" % x.shape[0])
             seeds = seeds.to(device=x.device, dtype=torch.int64).contiguous()
             chain_len = x[0].numel()
+        if (self.graph and philox and not record and self.prior_solver != 'exact'
+                and self.nan_check == 'deferred' and self.num_steps > 1):
+            self._graph_loop(x, xt_k, self._kernel_tensor(self.prior_score, x), operator, measurement,
+                             params, seeds, chain_len, nan_flag)
+            if nan_flag.item():
+                return self._nan_result(x)
+            return x.detach()
         for _ in range(self.num_steps):
             grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
             prior = self.get_prior_score(x, x0hat, xt, model, sigma)
@@ -246,6 +261,35 @@ class MCMCSampler(nn.Module):
         if self.nan_check == 'deferred' and nan_flag.item():
             return self._nan_result(x)
         return x.detach()
+
+    def _graph_loop(self, x, xt_k, prior, operator, measurement, params, seeds, chain_len, nan_flag):
+        """num_steps steps in place on x: one eager, one captured, num_steps - 2 replays."""
+        dev = x.device
+        step_dev = torch.full((1,), self.noise_step, dtype=torch.int64, device=dev)
+        vel = self.velocity if self.mc_algo == 'hmc' else None
+        n = x.numel()
+
+        def one_step():
+            grad = operator.gradient(x, measurement)
+            rc = _lib.lib().mcmc_update_philox(
+                x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), xt_k.data_ptr(),
+                prior.data_ptr(), n, C.byref(params), seeds.data_ptr(), chain_len, 0,
+                step_dev.data_ptr(), None, nan_flag.data_ptr(), _lib.stream_of(x))
+            _lib.check(rc, "mcmc_update_philox")
+            step_dev.add_(1)
+
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            one_step()                                   # eager: also warms every allocation size
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                one_step()                               # recorded, not run
+            for _ in range(self.num_steps - 1):
+                graph.replay()
+        cur.wait_stream(side)
+        self.noise_step += self.num_steps
 
     def sample_MH(self, xt, model, x0hat, operator, measurement, sigma, ratio, record=False,
                   verbose=False):

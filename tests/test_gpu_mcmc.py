@@ -195,3 +195,47 @@ def test_update_kernel_on_a_large_state(algo, momentum, chunked, dev):
                 assert torch.equal(vel, v0)                    # momentum 0: the velocity is not stored
     assert (x - want).abs().max().item() <= 1e-5
     assert flag.item() == 0
+
+
+@pytest.mark.parametrize("task,algo,momentum,solver", [("blackhole", "hmc", 0.0, "gaussian"),
+                                                       ("blackhole", "langevin", 0.9, "score-min"),
+                                                       ("mri", "hmc", 0.83, "gaussian")])
+def test_graph_replayed_loop_equals_the_eager_loop(task, algo, momentum, solver, dev):
+    """MCMCSampler(graph=True): one eager step + a captured step replayed num_steps - 1 times
+    gives bit for bit what the eager Philox loop gives (same kernels, same arguments; the step
+    number travels in a device word), on two consecutive calls (the Philox counter runs on)."""
+    from step_amd.sampler import MCMCSampler
+    gen = torch.Generator(device=dev).manual_seed(11)
+    if task == "blackhole":
+        from tests.test_gpu_fused_step import make
+        op = make(dev, 6, 64)
+        shape = (3, 64, 1, 64, 64)
+        y = op(torch.rand(1, *shape[1:], device=dev, generator=gen) * 2 - 1)
+        x0 = torch.rand(*shape, device=dev, generator=gen) * 2 - 1
+        lr = float(1e-3 / op.gradient(x0, y).abs().max())
+    else:
+        from step_amd.forward_operator import get_operator
+        op = get_operator("mri", acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+        shape = (2, 12, 2, 192, 192)
+        y = op(torch.randn(1, *shape[1:], device=dev, generator=gen))
+        x0 = torch.randn(*shape, device=dev, generator=gen)
+        lr = 1e-6
+    xt = x0 + 0.1 * torch.randn(*shape, device=dev, generator=gen)
+    model = ToyModel(shape[1:], factor=2, gain=1.5).to(dev) if solver != "gaussian" else None
+    seeds = torch.arange(shape[0], device=dev, dtype=torch.int64) * 7919 + 5
+    outs = []
+    for graph in (False, True):
+        mc = MCMCSampler(num_steps=7, lr=lr, tau=0.5, prior_solver=solver, mc_algo=algo, momentum=momentum,
+                         noise="philox", graph=graph)
+        mc.set_chains(seeds=seeds)
+        if algo == "hmc":                            # the start velocity comes from torch's generator
+            torch.manual_seed(123)
+        a = mc.sample(xt, model, x0, op, y, 0.7, 0.1)
+        if algo == "hmc":
+            torch.manual_seed(124)
+        b = mc.sample(xt, model, a, op, y, 0.6, 0.2)
+        assert mc.noise_step == 14
+        outs.append((a, b))
+    assert not torch.equal(outs[0][0], x0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
