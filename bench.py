@@ -345,7 +345,8 @@ def main():
             gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                        traffic=measured_traffic("k_mri_loss_grad2", B == 256),
+                        traffic=(measured_traffic("k_mri_loss_grad2p", B == 256)
+                                 or measured_traffic("k_mri_loss_grad2", B == 256)),
                         algorithmic="24*T*R*R bytes per chain x %d chains" % B, kernels_ms=kern)
         out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
                    unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,

@@ -270,9 +270,12 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
  * grad may be NULL (loss only).  chain_scale may be NULL (=1).
  * loss_part: workspace float[2*B*T] (per-frame partial losses, then shares of the masked-out
  * rows' sum |y|^2 of a batch-1 measurement); loss [B]; loss_total (may be NULL): sum of loss[].
- * variant: 0 = choose by mask (the software-pipelined kernel when every mask frame keeps <= 64
- * rows, i.e. every shipped mode), 1 = first-generation kernel (any mask; cross-checks),
- * 2 = pipelined kernel (STEP_E_INVALID if a mask frame keeps more than 64 rows),
+ * variant: 0 = choose by mask and measurement (when every mask frame keeps <= 64 rows, i.e. every
+ * shipped mode: the persistent pipelined kernel for y_batch = 1, the pipelined kernel otherwise),
+ * 1 = first-generation kernel (any mask; cross-checks),
+ * 2 = pipelined kernel, one workgroup per frame (STEP_E_INVALID if a mask frame keeps more than 64 rows),
+ * 4 = its persistent form (a workgroup walks several frames and requests the next frame's first
+ * strips under the current frame's row and inverse phases; y_batch = 1 only; bit-identical to 2),
  * 3 = in-register column transforms with two workgroups per CU (<= 52 kept rows per frame; same
  * results to rounding; measured slower than 2 so far and never chosen by 0). */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,

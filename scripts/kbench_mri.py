@@ -9,7 +9,7 @@ dev = 'cuda:0'
 tag = os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else 'libstep_amd.so'
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tag += ' v%d' % variant
-for mode, yb in (("same_mask", 1), ("split_mask", 1), ("same_mask", 0)):
+for mode, yb in (("same_mask", 1), ("split_mask", 1)) + (() if variant == 4 else (("same_mask", 0),)):
     op = get_operator("mri", acc_factor=6, mode=mode, resolution=192, frames=12, num_acs_lines=24)
     op.kernel_variant = variant
     for B in (32, 64, 256):

@@ -79,7 +79,7 @@ class DynamicMRI(Operator):
         self._dev_tables = {}
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
-    kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined, 3 two per CU
+    kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined, 3 two per CU, 4 persistent
 
     def _tables(self, device):
         key = str(device)

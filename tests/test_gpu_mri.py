@@ -209,3 +209,25 @@ def test_two_per_cu_kernel_matches_pipelined_and_oracle(mode, acc, acs, ybatch, 
     g_ref, _ = orc.gradient(x[:nb], yb[:nb], return_loss=True)
     assert_close(g3[:nb], g_ref, RTOL, "gradient vs the oracle")
     assert_close(loss3[:nb], orc.loss(x[:nb], yb[:nb]), RTOL, "loss vs the oracle")
+
+
+@pytest.mark.parametrize("mode,acc,acs,B", [("same_mask", 6, 24, 17), ("same_mask", 6, 24, 50),
+                                            ("split_mask", 8, 12, 45), ("random_split_mask", 6, 24, 70)])
+def test_persistent_kernel_is_bit_identical_to_the_pipelined_one(mode, acc, acs, B, dev):
+    """variant 4 (mri_lg2p.h: a workgroup walks several frames, the next frame's first strips
+    travel under the current frame's row and inverse phases) runs the arithmetic of variant 2 in the
+    same order: identical bits, with one frame per workgroup (B*T < CUs), several, and ragged."""
+    op = make_op(mode, acc_factor=acc, num_acs_lines=acs)
+    gen = torch.Generator().manual_seed(17 * acc + B)
+    x = torch.randn(B, 12, 2, 192, 192, generator=gen).to(dev)
+    y = (op(torch.randn(1, 12, 2, 192, 192, generator=gen).to(dev))
+         + 0.1 * torch.randn(1, 12, 2, 192, 192, generator=gen).to(dev))
+    w = torch.linspace(0.5, 1.5, B, device=dev)
+    res = {}
+    for v in (2, 4):
+        op.kernel_variant = v
+        g, l = op.gradient(x, y, return_loss=True)
+        res[v] = (g, l, op.loss(x, y))
+    assert torch.equal(res[4][0], res[2][0])
+    assert torch.equal(res[4][2], res[2][2])
+    assert torch.equal(res[4][1], res[2][1])
