@@ -60,6 +60,12 @@ class DynamicMRI(Operator):
         self.acc_factor = acc_factor
         if mode not in _MODES:
             raise ValueError('Unknown mode: {}'.format(mode))
+        if int(resolution) != 192:
+            # the masks (host tables) exist at any size, the kernels for R = 192 (the shipped
+            # configuration) only: say so here, not at the first call
+            import warnings
+            warnings.warn("step_amd DynamicMRI: the kernels are built for resolution=192 only; with "
+                          "resolution=%r the mask is available, __call__ / loss / gradient will raise" % (resolution,))
         self.mode, self.resolution, self.frames = mode, resolution, frames
         mf = 1 if mode == 'same_mask' else frames
         m = np.zeros((mf, resolution), np.float32)
