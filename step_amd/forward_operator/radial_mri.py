@@ -178,18 +178,20 @@ class RadialMRI(Operator):
             outs.append(out)
         return torch.cat(outs) if len(outs) > 1 else outs[0]
 
-    def _type1(self, vals, out_scale, chain_scale=None):
-        """samples [B, T, J, 2] -> image [B, T, 2, R, R] (the exact adjoint of _type2)."""
+    def _type1(self, vals, out_scale, chain_scale=None, out=None):
+        """samples [B, T, J, 2] -> image [B, T, 2, R, R] (the exact adjoint of _type2); written
+        into ``out`` (contiguous, same shape) when given."""
         vals = vals.to(torch.float32).contiguous()
         B, T, R, G = vals.shape[0], self.frames, self.resolution, 2 * self.resolution
-        out = torch.empty(B, T, 2, R, R, device=vals.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(B, T, 2, R, R, device=vals.device, dtype=torch.float32)
         L, plan, st = _lib.lib(), self._plan(vals.device), _lib.stream_of(vals)
         for i in range(0, B, self.max_chunk):
             vc = vals[i:i + self.max_chunk]
             n = vc.shape[0]
             grid = torch.empty(n, T, G, G, device=vals.device, dtype=torch.complex64)
             _lib.check(L.nufft_spread(vc.data_ptr(), n * T, T, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
-            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse
+            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse (in place measured slower)
             cs = None if chain_scale is None else chain_scale[i:i + n].contiguous()
             _lib.check(L.nufft_crop_apod(Z.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
                                          out[i:i + n].data_ptr(), st), "nufft_crop_apod")
@@ -221,7 +223,7 @@ class RadialMRI(Operator):
             _lib.check(rc, "nufft_interp")
             if need_grad:
                 del Xg
-                grad[i:i + n] = self._type1(res, 1.0)
+                self._type1(res, 1.0, out=grad[i:i + n])
         if t0 is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(torch.cuda.current_stream(dev))
