@@ -97,6 +97,8 @@ SIGNATURES = {
     "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                c_p, c_p, c_p]),
+    "mri_coil_mul": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "mri_coil_combine": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "nufft_interp_blocks": (c_i, [c_i]),
     "nufft_pad_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
     "nufft_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),

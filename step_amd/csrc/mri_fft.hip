@@ -581,6 +581,72 @@ __global__ __launch_bounds__(MRI_THREADS) void k_mri_forward_mc(
     }
 }
 
+// ------------------------------------------------------------------ multi-coil, split path
+// z[f][c] = S_c * x[f] and grad[f] = sum_c conj(S_c) * g[f][c] as streaming kernels around the
+// single-coil step kernel, which then sees B x (T C) frames: per coil the frame's pixels cross HBM
+// four times (z written and read, g written and read) instead of the fused kernel's x, S_c and
+// running gradient per coil through one workgroup -- but on the pipelined, persistent kernel.
+// x, grad: [nframes][2][RR]; sens: [C][2][RR]; z, g: [nframes][C][2][RR]; RR % 4 == 0.
+__global__ __launch_bounds__(256) void k_mri_coil_mul(const float4* __restrict__ x, const float4* __restrict__ sens,
+                                                      int C, int rr4, float4* __restrict__ z) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rr4) return;
+    const float4 a = x[((size_t)f * 2 + 0) * rr4 + i], b = x[((size_t)f * 2 + 1) * rr4 + i];
+    for (int c = 0; c < C; ++c) {
+        const float4 p = sens[((size_t)c * 2 + 0) * rr4 + i], q = sens[((size_t)c * 2 + 1) * rr4 + i];
+        float4 zr, zi;
+        zr.x = a.x * p.x - b.x * q.x; zi.x = a.x * q.x + b.x * p.x;
+        zr.y = a.y * p.y - b.y * q.y; zi.y = a.y * q.y + b.y * p.y;
+        zr.z = a.z * p.z - b.z * q.z; zi.z = a.z * q.z + b.z * p.z;
+        zr.w = a.w * p.w - b.w * q.w; zi.w = a.w * q.w + b.w * p.w;
+        float4* o = z + (((size_t)f * C + c) * 2) * rr4 + i;
+        o[0] = zr;
+        o[rr4] = zi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mri_coil_combine(const float4* __restrict__ g, const float4* __restrict__ sens,
+                                                          int C, int rr4, float4* __restrict__ out) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rr4) return;
+    float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), si = sr;
+    for (int c = 0; c < C; ++c) {                              // fixed coil order
+        const float4 p = sens[((size_t)c * 2 + 0) * rr4 + i], q = sens[((size_t)c * 2 + 1) * rr4 + i];
+        const float4* gi = g + (((size_t)f * C + c) * 2) * rr4 + i;
+        const float4 u = gi[0], v = gi[rr4];
+        sr.x += u.x * p.x + v.x * q.x; si.x += v.x * p.x - u.x * q.x;      // conj(S) * (u + i v)
+        sr.y += u.y * p.y + v.y * q.y; si.y += v.y * p.y - u.y * q.y;
+        sr.z += u.z * p.z + v.z * q.z; si.z += v.z * p.z - u.z * q.z;
+        sr.w += u.w * p.w + v.w * q.w; si.w += v.w * p.w - u.w * q.w;
+    }
+    out[((size_t)f * 2 + 0) * rr4 + i] = sr;
+    out[((size_t)f * 2 + 1) * rr4 + i] = si;
+}
+
+extern "C" int mri_coil_mul(const float* x, const float* sens, int C, int nframes, int R, float* z,
+                            void* stream) {
+    STEP_REQUIRE(x && sens && z && C > 0 && nframes > 0, "mri_coil_mul: null pointer / sizes");
+    STEP_REQUIRE(R > 0 && (R * R) % 4 == 0 && nframes <= 65535, "mri_coil_mul: R = %d, %d frames (<= 65535)", R, nframes);
+    STEP_REQUIRE((((uintptr_t)x | (uintptr_t)sens | (uintptr_t)z) & 15) == 0, "mri_coil_mul: 16-byte aligned buffers");
+    const int rr4 = R * R / 4;
+    hipLaunchKernelGGL(k_mri_coil_mul, dim3((rr4 + 255) / 256, nframes), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (const float4*)sens, C, rr4, (float4*)z);
+    STEP_CHECK_LAUNCH("mri_coil_mul");
+    return STEP_OK;
+}
+
+extern "C" int mri_coil_combine(const float* g, const float* sens, int C, int nframes, int R, float* out,
+                                void* stream) {
+    STEP_REQUIRE(g && sens && out && C > 0 && nframes > 0, "mri_coil_combine: null pointer / sizes");
+    STEP_REQUIRE(R > 0 && (R * R) % 4 == 0 && nframes <= 65535, "mri_coil_combine: R = %d, %d frames (<= 65535)", R, nframes);
+    STEP_REQUIRE((((uintptr_t)g | (uintptr_t)sens | (uintptr_t)out) & 15) == 0, "mri_coil_combine: 16-byte aligned buffers");
+    const int rr4 = R * R / 4;
+    hipLaunchKernelGGL(k_mri_coil_combine, dim3((rr4 + 255) / 256, nframes), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g, (const float4*)sens, C, rr4, (float4*)out);
+    STEP_CHECK_LAUNCH("mri_coil_combine");
+    return STEP_OK;
+}
+
 // loss[b] = sum_t part[b][t] + sum of unk[0 .. n_unk): the shares of the masked-out rows' |y|^2
 // of a batch-1 measurement, which the pipelined kernel sums once for all chains (n_unk = 0
 // when the partial losses already hold them); total (optional) = sum_b loss[b], the scalar that

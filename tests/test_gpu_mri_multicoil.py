@@ -18,12 +18,17 @@ def make(mode, **kw):
     return get_operator("mri_multicoil", mode=mode, **dict(CFG, **kw))
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("mode", ["same_mask", "split_mask"])
-def test_single_coil_unit_sensitivity_is_the_single_coil_kernel(mode, dev):
+def test_single_coil_unit_sensitivity_is_the_single_coil_kernel(mode, split, dev):
+    """C = 1, S = 1: the split path (coil multiply -> single-coil step -> coil combine) gives the
+    bits of the single-coil operator's default kernel, the fused kernel those of its
+    first-generation kernel."""
     from step_amd.forward_operator import get_operator
     sens = torch.ones(1, 192, 192, dtype=torch.complex64)
     mc, sc = make(mode, sens=sens), get_operator("mri", mode=mode, **CFG)
-    sc.kernel_variant = 1                                   # the first-generation kernel
+    mc.split_coils = split
+    sc.kernel_variant = 0 if split else 1
     gen = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
     y = sc(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)) + 0.1 * torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)
@@ -32,15 +37,17 @@ def test_single_coil_unit_sensitivity_is_the_single_coil_kernel(mode, dev):
     g0, l0 = sc.gradient(x, y, return_loss=True)
     assert torch.equal(g1, g0) and torch.equal(l1, l0)
     assert torch.equal(mc.loss(x, y.unsqueeze(2)), sc.loss(x, y))
-    sc.kernel_variant = 0                                   # and the pipelined kernel to rounding
-    assert_close(g1, sc.gradient(x, y), 1e-5, "vs pipelined kernel")
+    sc.kernel_variant = 1 if split else 0                   # and the other kernel to rounding
+    assert_close(g1, sc.gradient(x, y), 1e-5, "vs the other single-coil kernel")
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("C,mode,acc,acs", [(8, "same_mask", 6, 24), (3, "random_split_mask", 6, 24), (2, "same_mask", 2, 24)])
-def test_matches_the_coil_by_coil_oracle(C, mode, acc, acs, dev):
+def test_matches_the_coil_by_coil_oracle(C, mode, acc, acs, split, dev):
     from step_amd.forward_operator import birdcage_maps
     sens = birdcage_maps(C) * torch.polar(torch.ones(C, 1, 1), torch.linspace(0, 2, C).view(C, 1, 1))
     op = make(mode, acc_factor=acc, num_acs_lines=acs, sens=sens)
+    op.split_coils = split
     orc = MultiCoilMRIOracle(acc, mode, 192, 12, acs, sens)
     gen = torch.Generator().manual_seed(C)
     x = torch.randn(2, 12, 2, 192, 192, generator=gen)
