@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -224,17 +224,45 @@ typedef struct {               /* device workspace of the fused step (caller-own
     float* S;                  /* [B][T][4], 16-byte aligned */
 } bh_step_ws_t;
 
-typedef struct {               /* MCMCSampler.optimize's update fused into the adjoint (daps.py:210-223) */
+/* Constants of the state update (mcmc_update below; here because bh_update_t carries them). */
+typedef struct {
+    float inv_tau2;      /* 1/tau^2            daps.py:101 */
+    float inv_sigma2;    /* 1/sigma^2          daps.py:102 */
+    float lr;            /* get_lr(ratio)      daps.py:233-239 */
+    float sqrt_lr;       /* np.sqrt(lr)        daps.py:139 */
+    float sqrt_2lr;      /* np.sqrt(2 lr)      daps.py:137 */
+    float momentum;      /* daps.py:140 */
+    float noise_scale;   /* np.sqrt(2 (1 - momentum)) */
+    int32_t algo;        /* 0 = langevin, 1 = hmc, 2 = gradient descent of optimize() */
+} mcmc_params_t;
+
+typedef struct {               /* the state update fused into the adjoint: no gradient in HBM */
     float* x_inout;            /* the state: must be the `x` the step was evaluated at; updated in place */
     const float* x0hat;
-    float lr, inv_sigma2;      /* x -= lr * (g + (x - x0hat) * inv_sigma2), g = d loss / d x */
+    float lr, inv_sigma2;      /* mcmc == NULL: MCMCSampler.optimize (daps.py:210-223),
+                                * x -= lr * (g + (x - x0hat) * inv_sigma2), g = d loss / d x */
+    /* mcmc != NULL (host pointer, read during the call; lr / inv_sigma2 above are then unused):
+     * the step of MCMCSampler.sample (daps.py:93-104, :135-144) for algo 0 (langevin) or algo 1
+     * with momentum 0 (no velocity buffer: its old value has weight zero), with the score
+     *     -g * inv_tau2 + (x0hat - x) * inv_sigma2
+     * -- what the 'gaussian' prior solver's (xt - x)/sigma^2 + (x0hat - xt)/sigma^2 adds up to --
+     * and the noise drawn in the kernel: Philox4x32-10 keyed by seeds[b] (DEVICE int64 [B]),
+     * counter (column quad, step) = the numbers mcmc_update_philox draws with quad_w = W.  The
+     * result equals mcmc_update_philox(x, NULL, g, xt = x0hat, prior = NULL, ..., quad_w = W).
+     * step_dev (may be NULL): device int64 read instead of `step`; nan_flag (may be NULL): set
+     * to 1 when an updated element is NaN. */
+    const mcmc_params_t* mcmc;
+    const int64_t* seeds;
+    int64_t step;
+    const int64_t* step_dev;
+    int32_t* nan_flag;
 } bh_update_t;
 
 /* loss [B], chi2 [B][5] (may be NULL), loss_total (may be NULL) = sum of loss[],
  * grad [B][T][H*W] = out_scale * chain_scale[b] * d loss[b] / d x' with x' = 0.5 x + 0.5
  * (out_scale = 0.5 gives d loss / d x; chain_scale may be NULL).
  * Exactly one of `grad` and `update` is non-NULL: with `update` the gradient is not written
- * anywhere -- the adjoint applies the gradient-descent step to x where it would have stored it. */
+ * anywhere -- the adjoint applies the state update to x where it would have stored it. */
 int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri, int T, int F,
                       int H, int W, const float* x, int B, const bh_tables_t* tab,
                       const int32_t* frame_tab, const bh_meas_t* y, const bh_weights_t* w,
@@ -243,12 +271,11 @@ int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri,
                       const bh_update_t* update, void* stream);
 
 /* The three-kernel path's adjoint with the same fused update (see bh_update_t): replaces
- * bh_dft_adj_sep3 + mcmc_update(algo 2). */
+ * bh_dft_adj_sep3 + mcmc_update(algo 2) or + mcmc_update_philox. */
 int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
                            const float* gvis_c64, const float* gflux, const float* chain_scale,
-                           int B, float out_scale, float* x, const float* x0hat, float lr,
-                           float inv_sigma2, const float* sum_in, int sum_n, float* sum_out,
-                           void* stream);
+                           int B, float out_scale, const bh_update_t* update, const float* sum_in,
+                           int sum_n, float* sum_out, void* stream);
 
 /* ------------------------------------------------------------------ dynamic MRI
  * x, y, out: [B][T][2][R][R] fp32 (channel 0 = Re, 1 = Im); R == 192.
@@ -361,16 +388,7 @@ int mri_loss_grad_static(const float* x, const float* y, int y_batch, int B, int
 
 /* ------------------------------------------------------------------ MCMC state update */
 
-typedef struct {
-    float inv_tau2;      /* 1/tau^2            daps.py:101 */
-    float inv_sigma2;    /* 1/sigma^2          daps.py:102 */
-    float lr;            /* get_lr(ratio)      daps.py:233-239 */
-    float sqrt_lr;       /* np.sqrt(lr)        daps.py:139 */
-    float sqrt_2lr;      /* np.sqrt(2 lr)      daps.py:137 */
-    float momentum;      /* daps.py:140 */
-    float noise_scale;   /* np.sqrt(2 (1 - momentum)) */
-    int32_t algo;        /* 0 = langevin, 1 = hmc, 2 = gradient descent of optimize() */
-} mcmc_params_t;
+/* mcmc_params_t: defined above, next to bh_update_t */
 
 /* score = -grad*inv_tau2 + (xt - x)*inv_sigma2 + prior  (score_fn daps.py:93-104), then
  * mc_update daps.py:135-144 in place on x (and velocity for hmc).  Sets *nan_flag (int32,
@@ -391,12 +409,18 @@ int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, c
  * torch's random stream: parity with the reference's draws is statistical (the reference's
  * stream is replayed through mcmc_update with an explicit eps).
  * step_dev (may be NULL): device int64 holding the step, read instead of `step` (graph replay).
+ * quad_w: 0 = one generator call per four consecutive elements (call j -> elements 4j .. 4j+3);
+ * W > 0 = the chain is rows of W elements and a call covers four consecutive rows of one column
+ * (call (row / 4) * W + column, its k-th normal for row 4 (row / 4) + k) -- the layout the
+ * black-hole adjoint draws in when it applies the update itself (bh_update_t), so that a chain
+ * gets the same noise on both routes; costs four calls per four elements here.  W % 4 == 0,
+ * chain_len % (4 W) == 0.
  * eps_out (may be NULL): receives the noise that was used.  chain_len % 4 == 0, 16-byte aligned
  * buffers. */
 int mcmc_update_philox(float* x, float* velocity, const float* grad, const float* xt,
                        const float* prior, int64_t n, const mcmc_params_t* p, const int64_t* seeds,
-                       int64_t chain_len, int64_t step, const int64_t* step_dev, float* eps_out,
-                       int32_t* nan_flag, void* stream);
+                       int64_t chain_len, int64_t step, const int64_t* step_dev, int64_t quad_w,
+                       float* eps_out, int32_t* nan_flag, void* stream);
 
 #ifdef __cplusplus
 }

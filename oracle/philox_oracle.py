@@ -46,3 +46,12 @@ def chain_noise(seed, step, chain_len):
     n0, n1 = box_muller(r[:, 0], r[:, 1])
     n2, n3 = box_muller(r[:, 2], r[:, 3])
     return np.stack([n0, n1, n2, n3], -1).reshape(-1)
+
+
+def chain_noise_quad(seed, step, chain_len, width):
+    """The same draw in the column-quad layout (mcmc_update_philox with quad_w = width, and the
+    black-hole adjoint's in-kernel Langevin step): the chain is rows of `width` elements and
+    generator call (row // 4) * width + column supplies rows 4 (row // 4) .. + 3 of that column."""
+    assert width % 4 == 0 and chain_len % (4 * width) == 0
+    calls = chain_noise(seed, step, chain_len).reshape(chain_len // (4 * width), width, 4)
+    return np.ascontiguousarray(calls.transpose(0, 2, 1)).reshape(-1)

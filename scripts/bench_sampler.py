@@ -18,6 +18,7 @@ p.add_argument('--reps', type=int, default=5)
 p.add_argument('--latent', action='store_true')
 p.add_argument('--optimize', action='store_true', help='MCMCSampler.optimize (the pixel-space branch of LatentDAPS, daps.py:312)')
 p.add_argument('--noise', default='torch', choices=['torch', 'philox'])
+p.add_argument('--no-fuse', action='store_true', help='keep the Langevin update out of the adjoint (gradient + mcmc_update_philox)')
 p.add_argument('--graph', action='store_true', help='MCMCSampler(graph=True): the loop as replays of one captured step (philox noise)')
 a = p.parse_args()
 dev = torch.device('cuda:0')
@@ -42,6 +43,7 @@ class StandIn(torch.nn.Module):
 
 mc = MCMCSampler(num_steps=a.steps, lr=1.2e-5, tau=0.021, lr_min_ratio=0.015, prior_solver='gaussian',
                  mc_algo='hmc', momentum=0.0, noise=a.noise, graph=a.graph)
+mc.fuse_langevin = not a.no_fuse
 if a.noise == 'philox':
     mc.set_chains(seeds=torch.arange(37, 37 + a.batch, dtype=torch.int64, device=dev))
 if a.latent:

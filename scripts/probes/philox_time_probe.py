@@ -12,7 +12,7 @@ for B in (1, 8, 64):
         p = _lib.mcmc_params_t(1.0, 1.0, 1e-4, 1e-2, 1.4e-2, mom, 1.0, algo)
         st = torch.cuda.current_stream().cuda_stream
         def plain(): assert L.mcmc_update(x.data_ptr(), v.data_ptr(), g.data_ptr(), xt.data_ptr(), pr.data_ptr(), eps.data_ptr(), n, C.byref(p), flag.data_ptr(), st) == 0
-        def phil(): assert L.mcmc_update_philox(x.data_ptr(), v.data_ptr(), g.data_ptr(), xt.data_ptr(), pr.data_ptr(), n, C.byref(p), seeds.data_ptr(), n // B, 5, None, None, flag.data_ptr(), st) == 0
+        def phil(): assert L.mcmc_update_philox(x.data_ptr(), v.data_ptr(), g.data_ptr(), xt.data_ptr(), pr.data_ptr(), n, C.byref(p), seeds.data_ptr(), n // B, 5, None, 0, None, flag.data_ptr(), st) == 0
         for name, fn in (("plain", plain), ("philox", phil)):
             for _ in range(5): fn()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]

@@ -16,7 +16,7 @@ for B in (1, 8):
     seeds = torch.arange(B, dtype=torch.int64, device=dev); flag = torch.zeros(1, dtype=torch.int32, device=dev)
     def upd():
         rc = _lib.lib().mcmc_update_philox(x.data_ptr(), None, grad.data_ptr(), xt.data_ptr(), prior.data_ptr(), x.numel(),
-                                           C.byref(params), seeds.data_ptr(), x[0].numel(), 3, None, None, flag.data_ptr(), _lib.stream_of(x))
+                                           C.byref(params), seeds.data_ptr(), x[0].numel(), 3, None, 0, None, flag.data_ptr(), _lib.stream_of(x))
     def both():
         g = op.gradient(x, y, return_loss=True); upd()
     for name, fn in (("op.gradient", lambda: op.gradient(x, y, return_loss=True)), ("update kernel", upd), ("both", both)):

@@ -48,13 +48,15 @@ class nufft_plan_t(C.Structure):
                 ("tile_base", c_p), ("apod", c_p)]
 
 
-class bh_update_t(C.Structure):
-    _fields_ = [("x_inout", c_p), ("x0hat", c_p), ("lr", c_f), ("inv_sigma2", c_f)]
-
-
 class mcmc_params_t(C.Structure):
     _fields_ = [("inv_tau2", c_f), ("inv_sigma2", c_f), ("lr", c_f), ("sqrt_lr", c_f),
                 ("sqrt_2lr", c_f), ("momentum", c_f), ("noise_scale", c_f), ("algo", C.c_int32)]
+
+
+class bh_update_t(C.Structure):
+    _fields_ = [("x_inout", c_p), ("x0hat", c_p), ("lr", c_f), ("inv_sigma2", c_f),
+                ("mcmc", C.POINTER(mcmc_params_t)), ("seeds", c_p), ("step", C.c_int64),
+                ("step_dev", c_p), ("nan_flag", c_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/step_amd.h declares
@@ -82,8 +84,8 @@ SIGNATURES = {
     "bh_loss_grad_sep3": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, C.POINTER(bh_tables_t), c_p,
                                 C.POINTER(bh_meas_t), C.POINTER(bh_weights_t), C.POINTER(bh_step_ws_t),
                                 c_p, c_f, c_p, c_p, c_p, c_p, C.POINTER(bh_update_t), c_p]),
-    "bh_dft_adj_sep3_update": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_f, c_f,
-                                     c_p, c_i, c_p, c_p]),
+    "bh_dft_adj_sep3_update": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f,
+                                     C.POINTER(bh_update_t), c_p, c_i, c_p, c_p]),
     "bh_closure_loss": (c_i, [c_p, c_p, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
                               C.POINTER(bh_weights_t), c_p, c_p, c_p, c_p, c_p]),
     "bh_closure_chisq": (c_i, [c_p, c_p, c_i, c_i, C.POINTER(bh_tables_t), C.POINTER(bh_meas_t),
@@ -107,7 +109,7 @@ SIGNATURES = {
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                    c_p, c_p]),
     "mcmc_update_philox": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_i64,
-                                 c_i64, c_p, c_p, c_p, c_p]),
+                                 c_i64, c_p, c_i64, c_p, c_p, c_p]),
     "mcmc_update": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_p]),
 }
 

@@ -37,6 +37,7 @@
 //   24 MFMAs; no barrier and no vector load in the chain loop.
 #include "common.h"
 #include "closure_math.h"
+#include "mcmc_elem.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -173,10 +174,21 @@ struct S3FusedAdj {
 // MCMCSampler.optimize (daps.py:210-223), x -= lr (g + (x - x0hat) / sigma^2), is applied where
 // the tile would have been written: x and x0hat are read, x is written, and the gradient never
 // reaches HBM (one 1 GB write and one 1 GB read less per step at 64 chains).
+// UPD == 2 / 3: the Langevin / momentum-free HMC step of MCMCSampler.sample (daps.py:135-144,
+// :93-104 with the score terms that depend on x collapsed into (x0 - x) / sigma^2: what the
+// 'gaussian' prior solver's (xt - x) / sigma^2 + (x0hat - xt) / sigma^2 adds up to) in the same
+// place, noise from Philox in the column-quad layout (mcmc_elem.h): a lane's four accumulator
+// rows of one column are one generator call.  Same arithmetic as k_mcmc_update on the stored
+// gradient with xt = x0hat, no prior tensor and quad_w = W.
 struct S3Update {
     float* x;                 // [B][T][H*W] state, updated in place
     const float* x0;          // x0hat
     float lr, inv_sigma2;
+    mcmc_params_t p;          // UPD >= 2
+    const int64_t* seeds;     // [B] device
+    int64_t step;
+    const int64_t* step_dev;  // device step counter (graph replay) or null
+    int32_t* nan_flag;        // or null
 };
 
 // chi^2 sums of one chain -> loss and the backward factors (same order of operations as
@@ -461,7 +473,7 @@ extern "C" int bh_dft_fwd_sep3(const float* ey_t, const float* ex_ri, int T, int
 // [(((part*2 + kb)*3 + plane)*2 + h)][H/2 rows y]; part 0 = Re ey (with the flux row f = F,
 // ey = 1), part 1 = Im ey; kb = block of 16 baselines.  B operand per chain in registers:
 // wR[f][x] = Re(conj(ex) g) = exR gR + exI gI,  wI[f][x] = Im(conj(ex) g) = exR gI - exI gR.
-template <int H, int W, bool FUSED, bool UPD>
+template <int H, int W, bool FUSED, int UPD>
 __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const float* __restrict__ ey_ri, const float* __restrict__ ex_ri,
     const float* __restrict__ gvis, const float* __restrict__ gflux,
@@ -479,6 +491,8 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         if (threadIdx.x == 0) *sum_out = sacc;
     }
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
+    const uint64_t nstep = UPD >= 2 ? (uint64_t)(up.step_dev ? *up.step_dev : up.step) : 0;
+    bool bad = false;
     u32x4* eyp = lds4;
     float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
     float* fac = gl + S3_GCH * S3_GROW;                      // FUSED: [S3_GCH][2] backward factors, then [8]
@@ -488,6 +502,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     const int n_it = S3_NIT();
     const bool mine = strip < NSTRIP;                        // W < 256: the spare waves only stage
     const int xcol = (mine ? strip : 0) * 32 + li;
+    const uint64_t qbase = (uint64_t)t * (H / 4) * W + xcol; // UPD >= 2: this column's first quad of the frame
 
     // this lane's baselines f = 16 kb + 8 h + j and their ex values (chain independent); issued
     // ahead of the table staging so that the two cold fetches overlap
@@ -647,6 +662,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                 split3(wi, ih[kb], im[kb], il[kb]);
             }
             const size_t fo = ((size_t)b * T + t) * H * W + xcol;
+            const uint64_t seed = UPD >= 2 ? (uint64_t)up.seeds[b] : 0;
             float* gf = (UPD ? up.x : grad) + fo;
             const float* x0f = UPD ? up.x0 + fo : nullptr;
 #pragma unroll 1
@@ -669,7 +685,46 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                         }
                     }
                 const int ytop = tile * 32 + 4 * h;
-                if (UPD) {
+                if (UPD >= 2) {
+                    // eight rows (two quads) at a time: their state and x0hat are fetched, the two
+                    // generator calls run while the loads are in flight, then the update is stored
+#pragma unroll
+                    for (int part = 0; part < 4; ++part) {
+                        const bool mir = part >= 2;
+                        const int r0 = 8 * (part & 1);
+                        float xo[8], xh[8], nz[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int yy = ytop + (i & 3) + 8 * ((r0 + i) >> 2);
+                            xo[i] = gf[(mir ? H - 1 - yy : yy) * W];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int yy = ytop + (i & 3) + 8 * ((r0 + i) >> 2);
+                            xh[i] = x0f[(mir ? H - 1 - yy : yy) * W];
+                        }
+#pragma unroll
+                        for (int jq = 0; jq < 2; ++jq) {
+                            const int yq = ytop + 8 * ((r0 >> 2) + jq);          // first row of the quad, upper half
+                            const int m = (mir ? H - 4 - yq : yq) >> 2;
+                            float n4[4];
+                            philox_normals4(qbase + (uint64_t)m * W, nstep, seed, n4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) nz[4 * jq + k] = n4[mir ? 3 - k : k];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int r = r0 + i;
+                            const int yy = ytop + (r & 3) + 8 * (r >> 2);
+                            const float g_ = mir ? ev[r] - od[r] : ev[r] + od[r];
+                            float vdummy;
+                            const float xn = mcmc_elem_a<UPD - 2>(xo[i], g_, xh[i], 0.f, nz[i], 0.f, up.p, vdummy);
+                            bad |= (xn != xn);
+                            S3_STG(gf + (mir ? H - 1 - yy : yy) * W, xn);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (UPD == 1) {
                     // state and x0hat behind the matrix work, upper rows then mirror rows: 32 values
                     // in flight per lane next to the accumulators is what the register file takes;
                     // the other seven waves of the workgroup cover a wave's wait
@@ -704,6 +759,9 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
             }
         }
     }
+    if (UPD >= 2 && up.nan_flag && __any(bad) && lane == 0 &&
+        __hip_atomic_load(up.nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        atomicOr(up.nan_flag, 1);
     if (FUSED && blockIdx.x == 0) {
         // workgroup 0, once its tiles are stored (off the path of everybody's first store): every
         // chain's loss (and raw chi^2) and their total, in a fixed order:
@@ -755,10 +813,15 @@ static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, 
     hipLaunchKernelGGL((k_dft_adj_s3<H, W, FU, UP>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri, \
                        gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,    \
                        fz ? *fz : S3FusedAdj{}, up ? *up : S3Update{})
-    if (fz && up) { S3_ADJ_LAUNCH(true, true); }
-    else if (fz) { S3_ADJ_LAUNCH(true, false); }
-    else if (up) { S3_ADJ_LAUNCH(false, true); }
-    else { S3_ADJ_LAUNCH(false, false); }
+    const int mode = up ? (up->seeds ? 2 + up->p.algo : 1) : 0;     // 2: langevin, 3: hmc (momentum 0)
+    if (fz && mode == 3) { S3_ADJ_LAUNCH(true, 3); }
+    else if (mode == 3) { S3_ADJ_LAUNCH(false, 3); }
+    else if (fz && mode == 2) { S3_ADJ_LAUNCH(true, 2); }
+    else if (fz && mode == 1) { S3_ADJ_LAUNCH(true, 1); }
+    else if (fz) { S3_ADJ_LAUNCH(true, 0); }
+    else if (mode == 2) { S3_ADJ_LAUNCH(false, 2); }
+    else if (mode == 1) { S3_ADJ_LAUNCH(false, 1); }
+    else { S3_ADJ_LAUNCH(false, 0); }
 #undef S3_ADJ_LAUNCH
 }
 
@@ -786,20 +849,38 @@ extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, in
     return STEP_OK;
 }
 
-// bh_dft_adj_sep3 with MCMCSampler.optimize's update (daps.py:210-223) in place of the gradient
-// store: x[b][t][n] -= lr * (g + (x - x0hat) * inv_sigma2) with g = the gradient bh_dft_adj_sep3
-// would have written.
+// bh_update_t (checked) -> the kernel's argument block
+static int s3_make_update(const bh_update_t* u, int B, S3Update* out, const char* who) {
+    STEP_REQUIRE(u->x_inout && u->x0hat, "%s: update needs x_inout and x0hat", who);
+    *out = S3Update{};
+    out->x = u->x_inout; out->x0 = u->x0hat; out->lr = u->lr; out->inv_sigma2 = u->inv_sigma2;
+    if (!u->mcmc) return STEP_OK;
+    const mcmc_params_t& p = *u->mcmc;
+    STEP_REQUIRE(p.algo == 0 || (p.algo == 1 && p.momentum == 0.f),
+                 "%s: the in-adjoint step is langevin or hmc with momentum 0 (algo %d, momentum %g)", who,
+                 p.algo, (double)p.momentum);
+    STEP_REQUIRE(u->seeds, "%s: the in-adjoint Langevin step draws its noise from per-chain seeds", who);
+    STEP_REQUIRE(u->step >= 0, "%s: negative step", who);
+    out->p = p; out->seeds = u->seeds; out->step = u->step; out->step_dev = u->step_dev;
+    out->nan_flag = u->nan_flag;
+    return STEP_OK;
+}
+
+// bh_dft_adj_sep3 with the state update in place of the gradient store (bh_update_t):
+// MCMCSampler.optimize's x[b][t][n] -= lr * (g + (x - x0hat) * inv_sigma2) (daps.py:210-223) or,
+// with update->mcmc, the Langevin / momentum-free HMC step of MCMCSampler.sample with in-kernel
+// noise; g = the gradient bh_dft_adj_sep3 would have written.
 extern "C" int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, int T, int F, int H, int W,
                                       const float* gvis_c64, const float* gflux, const float* chain_scale,
-                                      int B, float out_scale, float* x, const float* x0hat, float lr,
-                                      float inv_sigma2, const float* sum_in, int sum_n, float* sum_out,
-                                      void* stream) {
-    STEP_REQUIRE(ey_ri && ex_ri && gvis_c64 && gflux && x && x0hat, "bh_dft_adj_sep3_update: null pointer");
+                                      int B, float out_scale, const bh_update_t* update,
+                                      const float* sum_in, int sum_n, float* sum_out, void* stream) {
+    STEP_REQUIRE(ey_ri && ex_ri && gvis_c64 && gflux && update, "bh_dft_adj_sep3_update: null pointer");
     STEP_REQUIRE(!sum_out || (sum_in && sum_n > 0), "bh_dft_adj_sep3_update: sum_out needs sum_in and sum_n > 0");
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_dft_adj_sep3_update: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3_update: image %dx%d not built (256, 128, 64 square)", H, W);
-    S3Update up{x, x0hat, lr, inv_sigma2};
+    S3Update up;
+    if (int rc = s3_make_update(update, B, &up, "bh_dft_adj_sep3_update")) return rc;
     dispatch_adj_s3(ey_ri, ex_ri, T, F, H, gvis_c64, gflux, chain_scale, B, out_scale, nullptr, sum_in, sum_n,
                     sum_out, nullptr, &up, (hipStream_t)stream);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3_update");
@@ -816,7 +897,10 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
     STEP_REQUIRE(ey_t && ey_ri && ex_ri && x && tab && frame_tab && y && w && ws && loss,
                  "bh_loss_grad_sep3: null pointer");
     STEP_REQUIRE((grad != nullptr) != (update != nullptr), "bh_loss_grad_sep3: pass either grad or update");
-    STEP_REQUIRE(!update || (update->x0hat && update->x_inout == x), "bh_loss_grad_sep3: update->x_inout must be x, x0hat non-null");
+    STEP_REQUIRE(!update || update->x_inout == x, "bh_loss_grad_sep3: update->x_inout must be x");
+    S3Update up{};
+    if (update)
+        if (int rc = s3_make_update(update, B, &up, "bh_loss_grad_sep3")) return rc;
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_loss_grad_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_loss_grad_sep3: image %dx%d not built (256, 128, 64 square)", H, W);
@@ -840,8 +924,6 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
     S3FusedAdj fa{(const float2*)ws->vis_c64, ws->flux, ws->S, ws->dcp, ws->dca, tab->cp_ptr, tab->cp_ent,
                   tab->ca_ptr, tab->ca_ent, y->flux, w->w_cp, w->w_camp, w->w_flux, w->normalize,
                   tab->n_tri, tab->n_quad, loss, chi2, loss_total};
-    S3Update up{};
-    if (update) up = S3Update{update->x_inout, update->x0hat, update->lr, update->inv_sigma2};
     dispatch_adj_s3(ey_ri, ex_ri, T, F, H, nullptr, nullptr, chain_scale, B, out_scale, grad, nullptr, 0,
                     nullptr, &fa, update ? &up : nullptr, st);
     STEP_CHECK_LAUNCH("bh_loss_grad_sep3 (adjoint)");

@@ -9,51 +9,9 @@
 // The python scalars of the reference (np.sqrt results, float64) enter fp32 tensor ops as fp32
 // scalars; here they arrive already rounded to fp32 in mcmc_params_t.
 #include "common.h"
-
-// One element of the update; `v_old` is only read when momentum != 0 (the shipped blackhole
-// configuration runs hmc with momentum 0, where the old velocity has weight zero).
-__device__ __forceinline__ float mcmc_elem(float xi, float g, float xti, float pr, float e, float v_old,
-                                           const mcmc_params_t& p, float& v_new) {
-    if (p.algo == 2) {   // MCMCSampler.optimize, daps.py:210-223: x -= lr (g + (x - x0hat) / sigma^2)
-        v_new = 0.f;
-        return xi - p.lr * (g + (xi - xti) * p.inv_sigma2);
-    }
-    const float s = -g * p.inv_tau2 + (xti - xi) * p.inv_sigma2 + pr;
-    if (p.algo == 0) {
-        v_new = 0.f;
-        return xi + p.lr * s + p.sqrt_2lr * e;
-    }
-    v_new = p.momentum * v_old + p.sqrt_lr * s + p.noise_scale * e;
-    return xi + v_new * p.sqrt_lr;
-}
+#include "mcmc_elem.h"
 
 #define MCMC_CHUNK_F4 16384      // float4 per array and chunk: 256 KB
-
-// ---- in-kernel noise: Philox4x32-10 (Salmon et al., SC'11), counter = (float4 index within the
-// chain, 0, step lo, step hi), key = the chain's 64-bit seed; four uniforms -> four normals by
-// Box-Muller.  A chain's noise depends only on (its seed, the step, the element): not on the
-// batch it is run in, the rank, or the launch geometry.  oracle/philox_oracle.py restates it.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
-        const uint32_t lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// (u32 a, u32 b) -> two independent N(0,1): radius from a (uniform in (0,1]), angle from b
-__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
-    const float u = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1], 24 bits: exact
-    const float r = sqrtf(-2.0f * logf(u));
-    float sn, cs;
-    sincospif((float)(b >> 8) * (2.0f / 16777216.0f), &sn, &cs);          // angle 2 pi b / 2^32
-    n0 = r * cs;
-    n1 = r * sn;
-}
 
 // VEC = 4: every pointer 16-byte aligned and n % 4 == 0 (float4 accesses); VEC = 1 otherwise.
 // grad / prior / eps are read once and never again: non-temporal, so that x and the velocity
@@ -64,6 +22,7 @@ struct McmcNoise {               // PHILOX instantiation only
     int64_t step;                // used when step_dev is null
     const int64_t* step_dev;     // device counter (graph replay): the step is read from here
     float* eps_out;              // optional: the noise that was used (recording, tests)
+    int64_t quad_w;              // 0: linear layout; > 0: column quads over rows of quad_w (mcmc_elem.h)
 };
 
 template <int VEC, bool PHILOX>
@@ -91,13 +50,23 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
             if (PHILOX) {
                 const int64_t b = i / nz.chain_f4, j = i - b * nz.chain_f4;
                 const uint64_t seed = (uint64_t)nz.seeds[b];
-                uint32_t r[4];
-                philox4x32_10((uint32_t)j, (uint32_t)((uint64_t)j >> 32), (uint32_t)step, (uint32_t)(step >> 32),
-                              (uint32_t)seed, (uint32_t)(seed >> 32), r);
-                float n0, n1, n2, n3;
-                box_muller(r[0], r[1], n0, n1);
-                box_muller(r[2], r[3], n2, n3);
-                e = f4{n0, n1, n2, n3};
+                float nn[4];
+                if (nz.quad_w == 0) {
+                    philox_normals4((uint64_t)j, step, seed, nn);
+                    e = f4{nn[0], nn[1], nn[2], nn[3]};
+                } else {
+                    // this float4 is one row of four neighbouring column quads: a call per column,
+                    // one normal of each (4 x the generator work; the path that needs this layout
+                    // at speed is the adjoint, whose lanes own whole quads)
+                    const int64_t e0 = 4 * j, row = e0 / nz.quad_w, col = e0 - row * nz.quad_w;
+                    const uint64_t q0 = (uint64_t)((row >> 2) * nz.quad_w + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        philox_normals4(q0 + k, step, seed, nn);
+                        const int c = (int)(row & 3);
+                        e[k] = c == 0 ? nn[0] : c == 1 ? nn[1] : c == 2 ? nn[2] : nn[3];
+                    }
+                }
                 if (nz.eps_out) ((f4*)nz.eps_out)[i] = e;
             } else if (eps) e = __builtin_nontemporal_load((const f4*)eps + i);
             const f4 xti = ((const f4*)xt)[i];
@@ -153,8 +122,8 @@ static int mcmc_blocks(int64_t n, bool vec) {
 extern "C" int mcmc_update_philox(float* x, float* velocity, const float* grad, const float* xt,
                                   const float* prior, int64_t n, const mcmc_params_t* p,
                                   const int64_t* seeds, int64_t chain_len, int64_t step,
-                                  const int64_t* step_dev, float* eps_out, int32_t* nan_flag,
-                                  void* stream) {
+                                  const int64_t* step_dev, int64_t quad_w, float* eps_out,
+                                  int32_t* nan_flag, void* stream) {
     STEP_REQUIRE(x && grad && xt && p && seeds, "mcmc_update_philox: null pointer");
     STEP_REQUIRE(p->algo == 0 || p->algo == 1, "mcmc_update_philox: algo %d draws no noise", p->algo);
     STEP_REQUIRE(p->algo != 1 || velocity, "mcmc_update_philox: hmc needs a velocity buffer");
@@ -162,10 +131,13 @@ extern "C" int mcmc_update_philox(float* x, float* velocity, const float* grad, 
                  "mcmc_update_philox: n = %lld must be whole chains of chain_len = %lld (a multiple of 4)",
                  (long long)n, (long long)chain_len);
     STEP_REQUIRE(step >= 0, "mcmc_update_philox: negative step");
+    STEP_REQUIRE(quad_w >= 0 && (quad_w == 0 || (quad_w % 4 == 0 && chain_len % (4 * quad_w) == 0)),
+                 "mcmc_update_philox: quad_w = %lld needs quad_w %% 4 == 0 and chains of whole groups of 4 rows",
+                 (long long)quad_w);
     const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
                          (uintptr_t)prior | (uintptr_t)eps_out;
     STEP_REQUIRE(al % 16 == 0, "mcmc_update_philox: buffers must be 16-byte aligned");
-    McmcNoise nz{seeds, chain_len / 4, step, step_dev, eps_out};
+    McmcNoise nz{seeds, chain_len / 4, step, step_dev, eps_out, quad_w};
     hipLaunchKernelGGL((k_mcmc_update<4, true>), dim3((unsigned)mcmc_blocks(n, true)), dim3(256), 0,
                        (hipStream_t)stream, x, velocity, grad, xt, prior, nullptr, n, *p, nan_flag, nz);
     STEP_CHECK_LAUNCH("mcmc_update_philox");

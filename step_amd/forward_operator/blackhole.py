@@ -480,21 +480,19 @@ class BlackHoleImagingTorch(Operator):
         """gvis [B, T*F, 2] fp32, gflux [B, T] -> grad [B, T, H*W] fp32.
         sum_of: a 1-d fp32 tensor whose sum the caller also wants (-> (grad, 0-d sum));
         on the sep3 path it rides along in the adjoint launch.
-        update = (x [B, T, H*W], x0hat, lr, inv_sigma2) (sep3 only): no gradient is written, the
-        adjoint applies x -= lr (g + (x - x0hat) inv_sigma2) in place and grad comes back None."""
+        update = a _lib.bh_update_t (sep3 only): no gradient is written, the adjoint applies the
+        state update in place on update.x_inout and grad comes back None."""
         B = gvis.shape[0]
         L, st = _lib.lib(), _lib.stream_of(gvis)
         cs = None if chain_scale is None else chain_scale.data_ptr()
         total = None
         if update is not None:
-            xv, x0, lr, inv_sigma2 = update
             if sum_of is not None:
                 total = torch.empty(1, device=self.device, dtype=torch.float32)
             t0 = self._tick()
             rc = L.bh_dft_adj_sep3_update(self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), self.T, self.F,
                                           self.H, self.W, gvis.data_ptr(), gflux.data_ptr(), cs, B,
-                                          out_scale, xv.data_ptr(), x0.data_ptr(), lr, inv_sigma2,
-                                          _lib.ptr(sum_of), 0 if sum_of is None else sum_of.numel(),
+                                          out_scale, C.byref(update), _lib.ptr(sum_of), 0 if sum_of is None else sum_of.numel(),
                                           _lib.ptr(total), st)
             self._tock("dft_adj", t0)
             _lib.check(rc, "bh_dft_adj_sep3_update")
@@ -588,9 +586,9 @@ class BlackHoleImagingTorch(Operator):
 
     def _fused_step(self, x, y, want_total=True, chain_scale=None, update=None):
         """The whole data step in two launches (bh_loss_grad_sep3): -> loss [B], total (0-d) or
-        None, grad [B, T, H*W] = d loss / d x.  update = (x0hat [B, T, H*W], lr, inv_sigma2): no
-        gradient is written (grad comes back None); the adjoint applies the descent step to x,
-        which must then be the caller's own contiguous fp32 storage."""
+        None, grad [B, T, H*W] = d loss / d x.  update = a _lib.bh_update_t on x: no gradient is
+        written (grad comes back None); the adjoint applies the state update to x, which must
+        then be the caller's own contiguous fp32 storage."""
         xv = self._video(x)
         B, M, T, dev = xv.shape[0], self.T * self.F, self.T, self.device
         Kcp, Kca = self.cphase_dim, self.logcamp_dim
@@ -598,13 +596,11 @@ class BlackHoleImagingTorch(Operator):
         sizes = (4 * B * T, 2 * B * M, B * T, B * Kcp, B * Kca, B, 5 * B, 4)
         buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
         S, vis, flux, dcp, dca, loss, chi2, total = torch.split(buf, sizes)
-        grad = upd = None
+        grad = None
         if update is None:
             grad = torch.empty(B, T, self.H * self.W, device=dev, dtype=torch.float32)
-        else:
-            if xv.data_ptr() != x.data_ptr():
-                raise ValueError("in-place update needs a contiguous fp32 state on the operator's device")
-            upd = _lib.bh_update_t(xv.data_ptr(), update[0].data_ptr(), update[1], update[2])
+        elif xv.data_ptr() != x.data_ptr() or update.x_inout != x.data_ptr():
+            raise ValueError("in-place update needs a contiguous fp32 state on the operator's device")
         ws = _lib.bh_step_ws_t(vis.data_ptr(), flux.data_ptr(), dcp.data_ptr(), dca.data_ptr(), S.data_ptr())
         meas, keep = self._meas(y)
         t0 = self._tick()
@@ -613,7 +609,7 @@ class BlackHoleImagingTorch(Operator):
             self.W, xv.data_ptr(), B, C.byref(self._tab), self._frame_tab.data_ptr(), C.byref(meas),
             C.byref(self._weights), C.byref(ws), _lib.ptr(chain_scale), 0.5, loss.data_ptr(),
             chi2.data_ptr(), total.data_ptr() if want_total else None, _lib.ptr(grad),
-            None if upd is None else C.byref(upd), _lib.stream_of(xv))
+            None if update is None else C.byref(update), _lib.stream_of(xv))
         self._tock("fused_step", t0)
         _lib.check(rc, "bh_loss_grad_sep3")
         self.last_chi2 = chi2.view(B, 5)
@@ -831,32 +827,56 @@ class BlackHoleImagingTorch(Operator):
         """descent_step lives in the folded 3xbf16 adjoint: the default path only."""
         return self.path == "sep3"
 
+    def _state_and_anchor(self, x, x0hat, who):
+        if self.path != "sep3":
+            raise NotImplementedError("%s is built on the sep3 kernels only" % who)
+        if (x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != self.device.type
+                or (self.device.index is not None and x.device.index != self.device.index)
+                or x.requires_grad):
+            raise ValueError("%s needs a contiguous fp32 state on %s without autograd history" % (who, self.device))
+        x0 = x0hat.detach()
+        if x0.dtype != torch.float32 or not x0.is_contiguous() or x0.shape != x.shape or x0.device != x.device:
+            x0 = x0.to(device=x.device, dtype=torch.float32).expand_as(x).contiguous()
+        if x0.data_ptr() == x.data_ptr():
+            raise ValueError("%s: x and x0hat must not share storage" % who)
+        return x0
+
+    def _step_with_update(self, x, y, upd, return_loss):
+        if self._fused_ok(y, x.shape[0]):
+            _, total, _ = self._fused_step(x, y, want_total=return_loss, update=upd)
+            return total
+        loss, gvis, gflux = self._loss_forward(x, y, True)
+        _, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss if return_loss else None, update=upd)
+        return total
+
     def descent_step(self, x, y, x0hat, lr, inv_sigma2, return_loss=False):
         """One step of MCMCSampler.optimize (daps.py:210-223) in place on x:
         ``x -= lr * (gradient(x, y) + (x - x0hat) * inv_sigma2)`` with the update applied by the
         adjoint kernel where it would have stored the gradient, which therefore never reaches HBM
         (per step and chain 4 video-sized streams instead of 6 + 2).  x: contiguous fp32 on the
         operator's device, modified; -> the summed loss at the old x (0-d) or None."""
-        if self.path != "sep3":
-            raise NotImplementedError("descent_step is built on the sep3 kernels only")
-        if (x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != self.device.type
-                or (self.device.index is not None and x.device.index != self.device.index)
-                or x.requires_grad):
-            raise ValueError("descent_step needs a contiguous fp32 state on %s without autograd history" % self.device)
-        x0 = x0hat.detach()
-        if x0.dtype != torch.float32 or not x0.is_contiguous() or x0.shape != x.shape or x0.device != x.device:
-            x0 = x0.to(device=x.device, dtype=torch.float32).expand_as(x).contiguous()
-        if x0.data_ptr() == x.data_ptr():
-            raise ValueError("descent_step: x and x0hat must not share storage")
-        lr, inv_sigma2 = float(lr), float(inv_sigma2)
-        if self._fused_ok(y, x.shape[0]):
-            _, total, _ = self._fused_step(x, y, want_total=return_loss, update=(x0, lr, inv_sigma2))
-            return total
-        loss, gvis, gflux = self._loss_forward(x, y, True)
-        xv = x.view(-1, self.T, self.H * self.W)
-        _, total = self._adjoint(gvis, gflux, None, 0.5, sum_of=loss if return_loss else None,
-                                 update=(xv, x0, lr, inv_sigma2))
-        return total
+        x0 = self._state_and_anchor(x, x0hat, "descent_step")
+        upd = _lib.bh_update_t(x.data_ptr(), x0.data_ptr(), float(lr), float(inv_sigma2))
+        return self._step_with_update(x, y, upd, return_loss)
+
+    has_langevin_step = has_descent_step
+
+    def langevin_step(self, x, y, x0hat, params, seeds, step=0, step_dev=None, nan_flag=None,
+                      return_loss=False):
+        """One step of MCMCSampler.sample (daps.py:184-200) in place on x for the 'gaussian' prior
+        solver, whose score terms add up to ``-g / tau^2 + (x0hat - x) / sigma^2``: langevin
+        (params.algo 0) or hmc with momentum 0 (algo 1), the update applied by the adjoint kernel
+        where it would have stored the gradient and the noise drawn there (Philox keyed by the
+        chain's seed, column-quad layout) -- neither gradient nor noise reaches HBM.  Equals
+        ``gradient`` + ``mcmc_update_philox(x, None, g, xt=x0hat, prior=None, ..., quad_w=W)``.
+        params: _lib.mcmc_params_t; seeds: int64 [B] on the device; step_dev: optional device
+        int64 read instead of ``step`` (graph replay); nan_flag: optional device int32."""
+        x0 = self._state_and_anchor(x, x0hat, "langevin_step")
+        if seeds.dtype != torch.int64 or seeds.numel() != x.shape[0] or seeds.device != x.device or not seeds.is_contiguous():
+            raise ValueError("langevin_step: seeds must be contiguous int64 [%d] on %s" % (x.shape[0], x.device))
+        upd = _lib.bh_update_t(x.data_ptr(), x0.data_ptr(), 0.0, 0.0, C.pointer(params), seeds.data_ptr(),
+                               int(step), _lib.ptr(step_dev), _lib.ptr(nan_flag))
+        return self._step_with_update(x, y, upd, return_loss)
 
 
 def thermal_measure(op, x, generator=None):

@@ -83,7 +83,11 @@ class MCMCSampler(nn.Module):
     ``noise``: 'torch' (default) draws epsilon with torch.randn_like as the reference does
     (daps.py:192), or chain by chain from ``set_chains(generators=...)``; 'philox' draws it inside
     the update kernel from per-chain seeds (``set_chains(seeds=...)``): no noise tensor in HBM,
-    per-chain reproducible, statistical parity only.
+    per-chain reproducible, statistical parity only.  With 'philox', the 'gaussian' prior solver,
+    no carried velocity (langevin, or hmc at momentum 0) and an operator that offers
+    ``langevin_step`` (the black-hole operator called on pixel-space frames), the whole step --
+    forward, chi^2, adjoint, score, noise, update -- is the operator's two or three launches and
+    neither the gradient nor the noise reaches HBM (``fuse_langevin``, on by default).
 
     ``graph``: with ``noise='philox'``, a prior score that is constant over the inner loop (every
     solver but 'exact') and an operator that is called directly (pixel-space state), the first step
@@ -115,6 +119,7 @@ class MCMCSampler(nn.Module):
         self.chain_seeds = None          # int64 [B] on the device ('philox'), or None
         self.noise_step = 0              # Philox counter: steps taken since set_chains
         self.fuse_descent = True         # optimize(): use operator.descent_step where offered
+        self.fuse_langevin = True        # sample(), noise='philox': use operator.langevin_step where offered
 
     def set_chains(self, generators=None, seeds=None):
         """Per-chain randomness for the next sample() calls: torch generators (start velocity,
@@ -224,33 +229,28 @@ class MCMCSampler(nn.Module):
         params = self._params(lr, sigma)
         nan_flag = torch.zeros(1, device=x.device, dtype=torch.int32)
         philox = self.noise == 'philox'
+        step_fn = None
         if philox:
             seeds = self.chain_seeds
             if seeds is None or seeds.numel() != x.shape[0]:
                 raise ValueError("noise='philox' needs set_chains(seeds=int64[%d])" % x.shape[0])
             seeds = seeds.to(device=x.device, dtype=torch.int64).contiguous()
-            chain_len = x[0].numel()
+            step_fn = self._philox_step_fn(x, xt_k, x0hat, operator, measurement, params, seeds, nan_flag,
+                                           record)
         if (self.graph and philox and not record and self.prior_solver != 'exact'
                 and self.nan_check == 'deferred' and self.num_steps > 1):
-            self._graph_loop(x, xt_k, self._kernel_tensor(self.prior_score, x), operator, measurement,
-                             params, seeds, chain_len, nan_flag)
+            self._graph_loop(x, step_fn)
             if nan_flag.item():
                 return self._nan_result(x)
             return x.detach()
         for _ in range(self.num_steps):
-            grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
-            prior = self.get_prior_score(x, x0hat, xt, model, sigma)
             if philox:
-                epsilon = torch.empty_like(x) if record else None
-                vel = self.velocity if self.mc_algo == 'hmc' else None
-                rc = _lib.lib().mcmc_update_philox(
-                    x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), xt_k.data_ptr(),
-                    self._kernel_tensor(prior, x).data_ptr(), x.numel(), C.byref(params), seeds.data_ptr(),
-                    chain_len, self.noise_step, None, _lib.ptr(epsilon), nan_flag.data_ptr(),
-                    _lib.stream_of(x))
-                _lib.check(rc, "mcmc_update_philox")
+                epsilon, fitting_loss = step_fn(self.noise_step, None,
+                                                self.get_prior_score(x, x0hat, xt, model, sigma))
                 self.noise_step += 1
             else:
+                grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
+                prior = self.get_prior_score(x, x0hat, xt, model, sigma)
                 epsilon = chain_randn_like(x, self.chain_generators)
                 self._fused_update(x, self._kernel_tensor(grad, x), xt_k,
                                    self._kernel_tensor(prior, x), epsilon, params, nan_flag)
@@ -262,20 +262,47 @@ class MCMCSampler(nn.Module):
             return self._nan_result(x)
         return x.detach()
 
-    def _graph_loop(self, x, xt_k, prior, operator, measurement, params, seeds, chain_len, nan_flag):
-        """num_steps steps in place on x: one eager, one captured, num_steps - 2 replays."""
-        dev = x.device
-        step_dev = torch.full((1,), self.noise_step, dtype=torch.int64, device=dev)
+    def _philox_step_fn(self, x, xt_k, x0hat, operator, measurement, params, seeds, nan_flag, record):
+        """-> step(step, step_dev, prior) taking one in-place step on x with in-kernel noise;
+        returns (epsilon or None, summed loss or None).  Two routes:
+        * the operator applies the update itself (``langevin_step``: the black-hole adjoint) when
+          the score is the 'gaussian' solver's -- its x-dependent terms collapse to
+          (x0hat - x) / sigma^2 -- and no velocity is carried (langevin, or hmc at momentum 0):
+          neither gradient nor noise reaches HBM;
+        * otherwise ``operator.gradient`` followed by ``mcmc_update_philox``."""
         vel = self.velocity if self.mc_algo == 'hmc' else None
-        n = x.numel()
+        n, chain_len = x.numel(), x[0].numel()
+        in_adjoint = (self.fuse_langevin and not record and self.prior_solver == 'gaussian'
+                      and (self.mc_algo == 'langevin' or self.momentum == 0)
+                      and getattr(operator, 'has_langevin_step', False))
+        if in_adjoint:
+            x0 = self._kernel_tensor(x0hat.detach(), x)
 
-        def one_step():
-            grad = operator.gradient(x, measurement)
+            def step(step, step_dev, prior=None):
+                operator.langevin_step(x, measurement, x0, params, seeds, step=step, step_dev=step_dev,
+                                       nan_flag=nan_flag)
+                return None, None
+            return step
+
+        def step(step, step_dev, prior):
+            grad, loss = operator.gradient(x, measurement, return_loss=True)
+            epsilon = torch.empty_like(x) if record else None
             rc = _lib.lib().mcmc_update_philox(
                 x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), xt_k.data_ptr(),
-                prior.data_ptr(), n, C.byref(params), seeds.data_ptr(), chain_len, 0,
-                step_dev.data_ptr(), None, nan_flag.data_ptr(), _lib.stream_of(x))
+                self._kernel_tensor(prior, x).data_ptr(), n, C.byref(params), seeds.data_ptr(), chain_len,
+                step, _lib.ptr(step_dev), 0, _lib.ptr(epsilon), nan_flag.data_ptr(), _lib.stream_of(x))
             _lib.check(rc, "mcmc_update_philox")
+            return epsilon, loss
+        return step
+
+    def _graph_loop(self, x, step_fn):
+        """num_steps steps in place on x: one eager, one captured, num_steps - 1 replays."""
+        dev = x.device
+        step_dev = torch.full((1,), self.noise_step, dtype=torch.int64, device=dev)
+        prior = self._kernel_tensor(self.prior_score, x)
+
+        def one_step():
+            step_fn(0, step_dev, prior)
             step_dev.add_(1)
 
         cur = torch.cuda.current_stream(dev)

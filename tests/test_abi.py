@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
-    assert _lib.lib().step_abi_version() == 4
+    assert _lib.lib().step_abi_version() == 5
 
 
 def test_host_entry_points_reject_bad_arguments():

@@ -25,7 +25,7 @@ def test_philox_kernel_matches_the_oracle(dev):
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     step = 2 ** 32 + 7                                         # the high word of the counter as well
     rc = _lib.lib().mcmc_update_philox(x.data_ptr(), vel.data_ptr(), g.data_ptr(), xt.data_ptr(), pr.data_ptr(),
-                                       x.numel(), C.byref(p), seeds.data_ptr(), L, step, None, eps.data_ptr(),
+                                       x.numel(), C.byref(p), seeds.data_ptr(), L, step, None, 0, eps.data_ptr(),
                                        flag.data_ptr(), _lib.stream_of(x))
     _lib.check(rc, "mcmc_update_philox")
     want = np.stack([chain_noise(int(s), step, L) for s in seeds.tolist()])
@@ -39,7 +39,7 @@ def test_philox_kernel_matches_the_oracle(dev):
     x2, vel2, eps2 = x0.clone(), v0.clone(), torch.empty_like(x)
     ctr = torch.tensor([step], dtype=torch.int64, device=dev)
     rc = _lib.lib().mcmc_update_philox(x2.data_ptr(), vel2.data_ptr(), g.data_ptr(), xt.data_ptr(), pr.data_ptr(),
-                                       x.numel(), C.byref(p), seeds.data_ptr(), L, 0, ctr.data_ptr(), eps2.data_ptr(),
+                                       x.numel(), C.byref(p), seeds.data_ptr(), L, 0, ctr.data_ptr(), 0, eps2.data_ptr(),
                                        flag.data_ptr(), _lib.stream_of(x))
     _lib.check(rc, "mcmc_update_philox")
     assert torch.equal(eps2, eps) and torch.equal(x2, x)
@@ -47,7 +47,7 @@ def test_philox_kernel_matches_the_oracle(dev):
     x3, eps3 = x0[1:2].clone(), torch.empty_like(x[1:2])
     rc = _lib.lib().mcmc_update_philox(x3.data_ptr(), v0[1:2].clone().data_ptr(), g[1:2].contiguous().data_ptr(),
                                        xt[1:2].contiguous().data_ptr(), pr[1:2].contiguous().data_ptr(), L, C.byref(p),
-                                       seeds[1:2].contiguous().data_ptr(), L, step, None, eps3.data_ptr(),
+                                       seeds[1:2].contiguous().data_ptr(), L, step, None, 0, eps3.data_ptr(),
                                        flag.data_ptr(), _lib.stream_of(x))
     _lib.check(rc, "mcmc_update_philox")
     assert torch.equal(eps3[0], eps[1]) and torch.equal(x3[0], x[1])

@@ -137,3 +137,111 @@ def test_optimize_with_and_without_the_fused_descent(dev):
     b = mc.optimize(x0, op, y, 0.7, 0.2)
     assert not torch.equal(a, x0)
     assert_close(a - x0, b - x0, 1e-4, "six descent steps")
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 33)])
+def test_langevin_step_equals_gradient_then_philox_update(n_sites, imsize, B, algo, dev):
+    """langevin_step (the step of MCMCSampler.sample for the 'gaussian' prior solver, applied and
+    its noise drawn inside the adjoint) == gradient() followed by mcmc_update_philox in the
+    column-quad noise layout with xt = x0hat and no prior tensor, on the two-launch path (B <= 31)
+    and on the three-kernel path; the noise itself against the numpy oracle."""
+    import ctypes as C
+    from oracle.philox_oracle import chain_noise_quad
+    from step_amd import _lib
+    op = make(dev, n_sites, imsize)
+    gen = torch.Generator(device=dev).manual_seed(200 + B)
+    x = torch.rand(B, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1
+    x0 = x + 0.05 * torch.randn(x.shape, device=dev, generator=gen)
+    y = op(torch.rand(1, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1)
+    g, total = op.gradient(x, y, return_loss=True)
+    gmax = float(g.abs().max())
+    lr = 1e-4
+    # data term, prior term and noise all of comparable size in the step
+    p = _lib.mcmc_params_t(30.0 / gmax, 40.0, lr, np.sqrt(lr), np.sqrt(2 * lr), 0.0, np.sqrt(2.0), algo)
+    seeds = torch.arange(B, device=dev, dtype=torch.int64) * 104729 + 2 ** 33 + 1
+    step = 2 ** 32 + 3
+    L = x[0].numel()
+    want, eps = x.clone(), torch.empty_like(x)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    vel = torch.zeros_like(x) if algo == 1 else None
+    rc = _lib.lib().mcmc_update_philox(want.data_ptr(), _lib.ptr(vel), g.data_ptr(), x0.data_ptr(), None, x.numel(),
+                                       C.byref(p), seeds.data_ptr(), L, step, None, imsize, eps.data_ptr(),
+                                       flag.data_ptr(), _lib.stream_of(x))
+    _lib.check(rc, "mcmc_update_philox")
+    b = B - 1
+    ref = chain_noise_quad(int(seeds[b]), step, L, imsize)
+    assert np.abs(eps[b].cpu().numpy().ravel() - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert abs(float(eps.mean())) < 5e-3 and abs(float(eps.std()) - 1) < 5e-3
+    got = x.clone()
+    got_total = op.langevin_step(got, y, x0, p, seeds, step=step, nan_flag=flag, return_loss=True)
+    assert_close(got_total, total, 1e-6, "loss at the old x")
+    assert flag.item() == 0
+    assert_close(got - x, want - x, 2e-5, "update")
+    assert (got - want).abs().max().item() <= 4e-7
+    # the step number from a device word (graph replay); another step gives other noise
+    got2 = x.clone()
+    ctr = torch.tensor([step], dtype=torch.int64, device=dev)
+    op.langevin_step(got2, y, x0, p, seeds, step=0, step_dev=ctr)
+    assert torch.equal(got2, got)
+    got3 = x.clone()
+    op.langevin_step(got3, y, x0, p, seeds, step=step + 1)
+    assert (got3 - got).abs().max().item() > 1e-3
+    # a chain's step does not depend on the batch it is in
+    if B > 1:
+        one = x[b:b + 1].clone()
+        op.langevin_step(one, y, x0[b:b + 1], p, seeds[b:b + 1].contiguous(), step=step)
+        assert_close(one - x[b:b + 1], got[b:b + 1] - x[b:b + 1], 2e-5, "chain alone")
+    # NaN guard
+    bad = x.clone()
+    x0n = x0.clone()
+    x0n[0, 3, 0, 5, 7] = float("nan")
+    op.langevin_step(bad, y, x0n, p, seeds, step=step, nan_flag=flag)
+    assert flag.item() == 1 and torch.isnan(bad).sum().item() == 1
+    with pytest.raises(RuntimeError):
+        pm = _lib.mcmc_params_t(1.0, 1.0, lr, np.sqrt(lr), np.sqrt(2 * lr), 0.5, 1.0, 1)
+        op.langevin_step(x.clone(), y, x0, pm, seeds, step=step)
+
+
+@pytest.mark.parametrize("algo", ["langevin", "hmc"])
+def test_sample_with_the_update_in_the_adjoint(algo, dev):
+    """MCMCSampler.sample(noise='philox', prior_solver='gaussian') through langevin_step equals the
+    same loop written out with gradient() + mcmc_update_philox, and switching the route off gives
+    a chain with the same statistics but other noise."""
+    import ctypes as C
+    from step_amd import _lib
+    from step_amd.sampler.daps import MCMCSampler
+    op = make(dev, 6, 64)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    B, steps, sigma, ratio = 4, 6, 0.7, 0.2
+    x0 = torch.rand(B, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1
+    xt = x0 + sigma * torch.randn(x0.shape, device=dev, generator=gen)
+    y = op(torch.rand(1, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1)
+    tau = 0.5
+    lr0 = float(1e-3 * tau ** 2 / op.gradient(x0, y).abs().max())
+    seeds = torch.arange(B, device=dev, dtype=torch.int64) * 31 + 9
+    mc = MCMCSampler(num_steps=steps, lr=lr0, tau=tau, prior_solver="gaussian", mc_algo=algo, momentum=0.0,
+                     noise="philox")
+    mc.set_chains(seeds=seeds)
+    torch.manual_seed(1)
+    a = mc.sample(xt, None, x0, op, y, sigma, ratio)
+    assert mc.noise_step == steps
+    params = mc._params(mc.get_lr(ratio), sigma)
+    want = x0.clone()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    for k in range(steps):
+        g = op.gradient(want, y)
+        rc = _lib.lib().mcmc_update_philox(want.data_ptr(), None if algo == "langevin" else torch.zeros_like(want).data_ptr(),
+                                           g.data_ptr(), x0.data_ptr(), None, want.numel(), C.byref(params),
+                                           seeds.data_ptr(), want[0].numel(), k, None, 64, None, flag.data_ptr(),
+                                           _lib.stream_of(want))
+        _lib.check(rc, "mcmc_update_philox")
+    assert not torch.equal(a, x0)
+    assert_close(a - x0, want - x0, 1e-4, "six steps")
+    mc.fuse_langevin = False
+    mc.set_chains(seeds=seeds)
+    torch.manual_seed(1)
+    b = mc.sample(xt, None, x0, op, y, sigma, ratio)
+    assert not torch.equal(a, b)
+    da, db = (a - x0).flatten(1), (b - x0).flatten(1)
+    assert_close(da.std(dim=1), db.std(dim=1), 2e-2, "step size of the two routes")

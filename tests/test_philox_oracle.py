@@ -2,7 +2,7 @@
 kat_vectors: philox4x32 10 rounds), and the statistics of the normals built on it."""
 import numpy as np
 
-from oracle.philox_oracle import chain_noise, philox4x32_10
+from oracle.philox_oracle import chain_noise, chain_noise_quad, philox4x32_10
 
 KAT = [  # counter, key, expected
     ((0x00000000,) * 4, (0x00000000,) * 2, (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
@@ -28,3 +28,12 @@ def test_normals_are_standard_and_chains_independent():
     assert abs(np.corrcoef(a, b)[0, 1]) < 0.01 and abs(np.corrcoef(a, c)[0, 1]) < 0.01
     assert abs(np.corrcoef(a[:-1], a[1:])[0, 1]) < 0.01
     assert np.array_equal(a, chain_noise(37, 0, 1 << 18))
+
+
+def test_quad_layout_is_a_permutation_of_the_linear_draw():
+    W, rows = 8, 12
+    a = chain_noise(5, 3, W * rows).reshape(-1, 4)               # [call][k]
+    q = chain_noise_quad(5, 3, W * rows, W).reshape(rows, W)
+    for row in range(rows):
+        for col in range(W):
+            assert q[row, col] == a[(row // 4) * W + col, row % 4]
