@@ -119,7 +119,9 @@ class MCMCSampler(nn.Module):
         self.chain_seeds = None          # int64 [B] on the device ('philox'), or None
         self.noise_step = 0              # Philox counter: steps taken since set_chains
         self.fuse_descent = True         # optimize(): use operator.descent_step where offered
-        self.fuse_langevin = True        # sample(), noise='philox': use operator.langevin_step where offered
+        # sample(), noise='philox': use operator.langevin_step where offered and where the operator
+        # prefers it at this batch (True), at any batch ('always'), or never (False)
+        self.fuse_langevin = True
 
     def set_chains(self, generators=None, seeds=None):
         """Per-chain randomness for the next sample() calls: torch generators (start velocity,
@@ -245,8 +247,8 @@ class MCMCSampler(nn.Module):
             return x.detach()
         for _ in range(self.num_steps):
             if philox:
-                epsilon, fitting_loss = step_fn(self.noise_step, None,
-                                                self.get_prior_score(x, x0hat, xt, model, sigma))
+                prior = self.get_prior_score(x, x0hat, xt, model, sigma) if step_fn.needs_prior else None
+                epsilon, fitting_loss = step_fn(self.noise_step, None, prior)
                 self.noise_step += 1
             else:
                 grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
@@ -274,7 +276,8 @@ class MCMCSampler(nn.Module):
         n, chain_len = x.numel(), x[0].numel()
         in_adjoint = (self.fuse_langevin and not record and self.prior_solver == 'gaussian'
                       and (self.mc_algo == 'langevin' or self.momentum == 0)
-                      and getattr(operator, 'has_langevin_step', False))
+                      and getattr(operator, 'has_langevin_step', False)
+                      and (self.fuse_langevin == 'always' or operator.prefers_langevin_step(x.shape[0])))
         if in_adjoint:
             x0 = self._kernel_tensor(x0hat.detach(), x)
 
@@ -282,24 +285,34 @@ class MCMCSampler(nn.Module):
                 operator.langevin_step(x, measurement, x0, params, seeds, step=step, step_dev=step_dev,
                                        nan_flag=nan_flag)
                 return None, None
+            step.needs_prior = False
             return step
+
+        # 'gaussian': (xt - x) / sigma^2 + (x0hat - xt) / sigma^2 is passed as (x0hat - x) / sigma^2
+        # (x0hat in the kernel's xt slot, no prior tensor): one video-sized stream less per step,
+        # and without the cancellation of the two xt terms (the noise is not the reference's
+        # stream on this route anyway; the torch-noise route keeps the reference's two terms)
+        x0_k = self._kernel_tensor(x0hat.detach(), x) if self.prior_solver == 'gaussian' else None
 
         def step(step, step_dev, prior):
             grad, loss = operator.gradient(x, measurement, return_loss=True)
             epsilon = torch.empty_like(x) if record else None
+            anchor = xt_k if x0_k is None else x0_k
             rc = _lib.lib().mcmc_update_philox(
-                x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), xt_k.data_ptr(),
-                self._kernel_tensor(prior, x).data_ptr(), n, C.byref(params), seeds.data_ptr(), chain_len,
+                x.data_ptr(), _lib.ptr(vel), self._kernel_tensor(grad, x).data_ptr(), anchor.data_ptr(),
+                None if x0_k is not None else self._kernel_tensor(prior, x).data_ptr(), n, C.byref(params),
+                seeds.data_ptr(), chain_len,
                 step, _lib.ptr(step_dev), 0, _lib.ptr(epsilon), nan_flag.data_ptr(), _lib.stream_of(x))
             _lib.check(rc, "mcmc_update_philox")
             return epsilon, loss
+        step.needs_prior = x0_k is None
         return step
 
     def _graph_loop(self, x, step_fn):
         """num_steps steps in place on x: one eager, one captured, num_steps - 1 replays."""
         dev = x.device
         step_dev = torch.full((1,), self.noise_step, dtype=torch.int64, device=dev)
-        prior = self._kernel_tensor(self.prior_score, x)
+        prior = self._kernel_tensor(self.prior_score, x) if step_fn.needs_prior else None
 
         def one_step():
             step_fn(0, step_dev, prior)

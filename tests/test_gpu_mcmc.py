@@ -227,6 +227,7 @@ def test_graph_replayed_loop_equals_the_eager_loop(task, algo, momentum, solver,
     for graph in (False, True):
         mc = MCMCSampler(num_steps=7, lr=lr, tau=0.5, prior_solver=solver, mc_algo=algo, momentum=momentum,
                          noise="philox", graph=graph)
+        mc.fuse_langevin = 'always'                  # first case: the update inside the adjoint
         mc.set_chains(seeds=seeds)
         if algo == "hmc":                            # the start velocity comes from torch's generator
             torch.manual_seed(123)
