@@ -198,6 +198,42 @@ def small_batch_line(op, y, dev, B, steps=2000):
                               algorithmic="whole step: 2 x 4*T*H*W bytes per chain x %d chains / ms_per_step" % B))
 
 
+def sampler_lines(op, y, dev, B, steps=30, reps=3):
+    """ms per step of the loops that call the operator -- MCMCSampler.sample and .optimize
+    (sampler/daps.py:178-223) on pixel-space frames, hmc at momentum 0 (the shipped black-hole
+    algorithm) with the 'gaussian' prior solver -- so that the driver's run also records what a
+    step costs with score, noise and update included.  The step size is one at which the chain
+    stays finite on this random start (asserted)."""
+    from step_amd.sampler.daps import MCMCSampler
+    g = torch.Generator(device=dev).manual_seed(2000 + B)
+    x0 = torch.rand(B, 64, 1, 256, 256, device=dev, generator=g) * 2 - 1
+    xt = x0 + 0.1 * torch.randn(x0.shape, device=dev, generator=g)
+    tau = 0.021
+    lr = float(1e-3 * tau ** 2 / op.gradient(x0, y).abs().max())
+    out = {}
+    for name, noise in (("sample_torch_noise", "torch"), ("sample_philox", "philox"), ("optimize", None)):
+        mc = MCMCSampler(num_steps=steps, lr=lr, tau=tau, lr_min_ratio=0.015, prior_solver="gaussian",
+                         mc_algo="hmc", momentum=0.0, noise=noise or "torch")
+        if noise == "philox":
+            mc.set_chains(seeds=torch.arange(37, 37 + B, dtype=torch.int64, device=dev))
+        run = (lambda: mc.optimize(x0, op, y, 0.5, 0.0)) if noise is None else \
+              (lambda: mc.sample(xt, None, x0, op, y, 0.5, 0.0))
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (reps * steps) * 1e3
+        assert torch.isfinite(res).all() and (res != 0).any(), "the chain diverged"
+        out[name] = dict(ms_per_step=ms, value=B / ms * 1e3, unit="chain-steps/s")
+        del res
+    out["config"] = dict(chains=B, steps=steps, algo="hmc, momentum 0", prior_solver="gaussian",
+                         note="sample_philox: update and noise inside the adjoint (langevin_step); "
+                              "optimize: update inside the adjoint (descent_step)")
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -369,6 +405,9 @@ def main():
             # the batches a GPU really sees: the reference runs B = 1 (sample.py:64-65) and config 4
             # on 8 GPUs is 64 / 8 = 8 chains per GPU.  Same operator, same step, own roofline.
             out["small_batches"] = {"B%d" % b: small_batch_line(op, y, dev, b) for b in (8, 1)}
+            del x
+            torch.cuda.empty_cache()
+            out["sampler_loop"] = sampler_lines(op, y, dev, B)
         if world == 1 and not a.no_cpu_baseline:
             if a.task == "blackhole":
                 out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)
