@@ -57,7 +57,7 @@ def parse():
     p.add_argument("--dry-run", action="store_true",
                    help="rank plumbing only (gloo, no GPU, no kernels): launch, barrier, MAX-reduce, JSON line")
     p.add_argument("--no-small-batches", action="store_true",
-                   help="skip the extra B = 8 / B = 1 measurements of the default blackhole run")
+                   help="skip the extra B = 8 / B = 1 and sampler-loop measurements of the default blackhole run")
     return p.parse_args()
 
 
