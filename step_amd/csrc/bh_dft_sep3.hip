@@ -850,7 +850,7 @@ extern "C" int bh_dft_adj_sep3(const float* ey_ri, const float* ex_ri, int T, in
 }
 
 // bh_update_t (checked) -> the kernel's argument block
-static int s3_make_update(const bh_update_t* u, int B, S3Update* out, const char* who) {
+static int s3_make_update(const bh_update_t* u, S3Update* out, const char* who) {
     STEP_REQUIRE(u->x_inout && u->x0hat, "%s: update needs x_inout and x0hat", who);
     *out = S3Update{};
     out->x = u->x_inout; out->x0 = u->x0hat; out->lr = u->lr; out->inv_sigma2 = u->inv_sigma2;
@@ -880,7 +880,7 @@ extern "C" int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, in
                  "bh_dft_adj_sep3_update: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_dft_adj_sep3_update: image %dx%d not built (256, 128, 64 square)", H, W);
     S3Update up;
-    if (int rc = s3_make_update(update, B, &up, "bh_dft_adj_sep3_update")) return rc;
+    if (int rc = s3_make_update(update, &up, "bh_dft_adj_sep3_update")) return rc;
     dispatch_adj_s3(ey_ri, ex_ri, T, F, H, gvis_c64, gflux, chain_scale, B, out_scale, nullptr, sum_in, sum_n,
                     sum_out, nullptr, &up, (hipStream_t)stream);
     STEP_CHECK_LAUNCH("bh_dft_adj_sep3_update");
@@ -900,7 +900,7 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
     STEP_REQUIRE(!update || update->x_inout == x, "bh_loss_grad_sep3: update->x_inout must be x");
     S3Update up{};
     if (update)
-        if (int rc = s3_make_update(update, B, &up, "bh_loss_grad_sep3")) return rc;
+        if (int rc = s3_make_update(update, &up, "bh_loss_grad_sep3")) return rc;
     STEP_REQUIRE(T > 0 && T <= 65535 && B > 0 && F > 0 && F <= 31,
                  "bh_loss_grad_sep3: need 1 <= F <= 31, 1 <= T <= 65535 (F=%d T=%d)", F, T);
     STEP_REQUIRE(bh_sep3_supported(H, W), "bh_loss_grad_sep3: image %dx%d not built (256, 128, 64 square)", H, W);

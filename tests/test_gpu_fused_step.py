@@ -198,9 +198,17 @@ def test_langevin_step_equals_gradient_then_philox_update(n_sites, imsize, B, al
     x0n[0, 3, 0, 5, 7] = float("nan")
     op.langevin_step(bad, y, x0n, p, seeds, step=step, nan_flag=flag)
     assert flag.item() == 1 and torch.isnan(bad).sum().item() == 1
-    with pytest.raises(RuntimeError):
-        pm = _lib.mcmc_params_t(1.0, 1.0, lr, np.sqrt(lr), np.sqrt(2 * lr), 0.5, 1.0, 1)
-        op.langevin_step(x.clone(), y, x0, pm, seeds, step=step)
+    # what the entry points refuse: a carried velocity, the optimize form, a negative step, bad seeds
+    for bad_p in (_lib.mcmc_params_t(1.0, 1.0, lr, np.sqrt(lr), np.sqrt(2 * lr), 0.5, 1.0, 1),
+                  _lib.mcmc_params_t(1.0, 1.0, lr, 0.0, 0.0, 0.0, 0.0, 2)):
+        with pytest.raises(RuntimeError, match="langevin or hmc with momentum 0"):
+            op.langevin_step(x.clone(), y, x0, bad_p, seeds, step=step)
+    with pytest.raises(RuntimeError, match="negative step"):
+        op.langevin_step(x.clone(), y, x0, p, seeds, step=-1)
+    with pytest.raises(ValueError):
+        op.langevin_step(x.clone(), y, x0, p, seeds[:1], step=step) if B > 1 else op.langevin_step(x.clone(), y, x0, p, seeds.int(), step=step)
+    with pytest.raises(ValueError):
+        op.langevin_step(got, y, got, p, seeds, step=step)
 
 
 @pytest.mark.parametrize("algo", ["langevin", "hmc"])
