@@ -25,6 +25,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libstep_amd.so does not export %s" % name
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/step_amd.h is a C header (the boundary has no C++ or torch types): it compiles as
+    strict C99, and the ctypes mirrors of its structs have the sizes the C compiler gives them."""
+    import subprocess
+    from step_amd import _lib
+    structs = ["bh_tables_t", "bh_meas_t", "bh_weights_t", "bh_step_ws_t", "bh_update_t", "mcmc_params_t",
+               "nufft_plan_t"]
+    structs = [n for n in structs if hasattr(_lib, n)]
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <stdio.h>\n#include "step_amd.h"\nint main(void) {\n'
+                   + "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in structs)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "hdr"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                    "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes = dict(zip(out[0::2], map(int, out[1::2])))
+    assert len(sizes) >= 5
+    for n, sz in sizes.items():
+        assert ctypes.sizeof(getattr(_lib, n)) == sz, n
+
+
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
