@@ -10,7 +10,9 @@ kwargs, sample.py:48-54).  ``--config`` takes the reference's own ``configs/task
 without it the shipped values of those files are used (TASKS below).  What the reference needs
 from outside and this build cannot have offline is replaced and SAID SO in the run's summary:
 the pretrained prior by ``StandInPrior`` (random weights), the test videos by synthetic ones, and
-ehtim by ``step_amd.eht_lite`` (array table) / ``measure()``'s restated noise model.
+ehtim by ``step_amd.eht_lite`` (array table) / ``measure()``'s restated noise model.  Every sample
+is scored by the task's evaluator (``step_amd.evaluate``; sample.py:71) and the summary carries the
+main metric's max / min / mean / std.
 
 Per test video the on-disk layout is the reference's: ``{out}/{idx:06d}/observations.pth``,
 ``videos.pth``, ``sample_{i}.pth`` (sample.py:59-67)."""
@@ -23,6 +25,7 @@ import numpy as np
 import torch
 
 from . import driver
+from .evaluate import get_evaluator
 from .forward_operator import get_operator
 from .prior_standin import StandInPrior
 from .sampler import get_sampler
@@ -160,9 +163,17 @@ def main(argv=None):
         if rank == 0:
             if a.out:
                 driver.write_sample_dir(os.path.join(a.out, "%06d" % idx), obs, samples, videos=video)
+            # the task's evaluator on every sample (sample.py:71; its wandb summary: max/min/mean/std)
+            evaluator = get_evaluator(a.task, op=op)
+            main = evaluator.main_eval_fn_name
+            with torch.no_grad():
+                vals = torch.cat([evaluator(video, obs, samples[i:i + 1].to(device))[main].reshape(-1).float().cpu()
+                                  for i in range(samples.shape[0])]).numpy()
             stats.append(dict(video=idx, seconds=dt, samples=a.num_samples,
                               samples_per_hour=3600.0 * a.num_samples / dt,
-                              finite=bool(torch.isfinite(samples).all())))
+                              finite=bool(torch.isfinite(samples).all()),
+                              metric=main, metric_max=float(vals.max()), metric_min=float(vals.min()),
+                              metric_mean=float(vals.mean()), metric_std=float(vals.std())))
             print(json.dumps(stats[-1]))
     if world > 1:
         torch.distributed.barrier()

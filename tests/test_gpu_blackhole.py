@@ -105,6 +105,12 @@ def test_chi2_terms_and_evaluator(name, golden, dev):
     assert set(evn) == {"cphase", "logcamp"}
     for k in evn:
         assert_close(evn[k], g["x_evaln_" + k], RTOL, "evaluate_chisq normalized " + k)
+    # the registered evaluator (evaluate.py:43-53) on the reference's own normalised chi^2
+    from step_amd.evaluate import get_evaluator
+    ev_obj = get_evaluator("blackhole", op=op)
+    assert ev_obj.main_eval_fn_name == "chisq" and ev_obj.name == "blackhole"
+    want = np.maximum(g["x_evaln_cphase"], g["x_evaln_logcamp"])
+    assert_close(ev_obj(None, y, x)["chisq"], want, RTOL, "BlackholeEvaluator")
     # fused per-chain raw chi^2 written by the loss kernel
     op.loss(x, y)
     w = g["weights"]

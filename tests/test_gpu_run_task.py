@@ -19,6 +19,11 @@ def test_run_task_end_to_end(task, shape, tmp_path, dev):
                            "--annealing-steps", "3", "--mcmc-steps", "4", "--diffusion-steps", "2",
                            "--max-batch", "2"])
     assert len(stats) == 2 and all(s["finite"] and s["samples"] == 3 for s in stats)
+    # every sample went through the task's evaluator (sample.py:71)
+    want = "chisq" if task == "blackhole" else "psnr"
+    for s in stats:
+        assert s["metric"] == want and s["metric_min"] <= s["metric_mean"] <= s["metric_max"]
+        assert all(v == v for v in (s["metric_min"], s["metric_max"], s["metric_std"]))
     for idx in (0, 1):
         d = out / ("%06d" % idx)
         assert sorted(os.listdir(d)) == ["observations.pth", "sample_0.pth", "sample_1.pth", "sample_2.pth", "videos.pth"]
