@@ -649,6 +649,19 @@ class BlackHoleImagingTorch(Operator):
         amp = vis.abs()
         return amp, self.sigma + 0 * amp
 
+    def forward_bisepectra_from_vis(self, vis):
+        """The three direction-corrected visibilities of every triangle (blackhole.py:341-353;
+        the reference's spelling).  Index arithmetic in torch: the kernels gather in place and
+        never materialise these; callers of the reference API get them here."""
+        legs = (vis[:, self.cp_index[:, k]] for k in range(3))
+        return tuple(self.correct_vis_direction(v, self.cp_conjugate[None, :, k]) for k, v in enumerate(legs))
+
+    def forward_logcamp_bispectra_from_vis(self, vis):
+        """The four amplitudes of every quadrangle (blackhole.py:365-380; the conjugate of a
+        modulus is the modulus, the correction is kept for the dtype it gives the reference)."""
+        legs = (vis[:, self.camp_index[:, k]].abs() for k in range(4))
+        return tuple(self.correct_vis_direction(v, self.camp_conjugate[None, :, k]) for k, v in enumerate(legs))
+
     def forward_cp_from_vis(self, vis):
         _, _, cp, scp, _, _ = self._observe(vis)
         return cp, scp
@@ -725,6 +738,22 @@ class BlackHoleImagingTorch(Operator):
                 v = chi2[:, i]
                 results[k] = self.normalize_chisq(v) if normalize else v
         return results
+
+    # 7. comparing two observations  (blackhole.py:613-649)
+    def cosine_similarity(self, a1, a2):
+        """min over the batch of |<a1, a2>|-like similarity: sum |a1 conj(a2)| / (|a1| |a2|)."""
+        a1, a2 = a1.flatten(1), a2.flatten(1)
+        return ((a1 * a2.conj()).abs().sum(1) / (torch.norm(a1, dim=1) * torch.norm(a2, dim=1))).min().item()
+
+    def compare(self, y1, y2, verbose=False):
+        """Field-by-field cosine similarity of two observations; returns the LARGEST of the nine,
+        as the reference does (blackhole.py:645-649)."""
+        names = ("vis", "sigmavis", "amp", "sigmaamp", "cphase", "sigmacp", "logcamp", "sigmacamp", "flux")
+        sims = {n: self.cosine_similarity(a, b) for n, a, b in zip(names, y1.to_list(), y2.to_list())}
+        if verbose:
+            for n in ("vis", "amp", "cphase", "logcamp", "flux", "sigmavis", "sigmaamp", "sigmacp", "sigmacamp"):
+                print("{} similarity: {:.3f} %".format(n, sims[n] * 100))
+        return max(sims.values())
 
     # 9. public interface  (blackhole.py:719-771)
     def unnormalize(self, inputs):
