@@ -372,6 +372,19 @@ int nufft_spread(const float* vals_c64, int nframes, int T, const nufft_plan_t* 
 int nufft_crop_apod(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
                     const float* chain_scale, float out_scale, float* out, void* stream);
 
+/* The grid transforms themselves for R = 192, G = 384 (nufft_grid_fft_supported), fused with the
+ * padding / cropping and pruned to the rows and columns that are not zero: 384 = 16 x 24 point
+ * passes, rows through LDS, columns 32 at a time.  NO REFERENCE COUNTERPART.
+ *   nufft_fwd_grid == nufft_pad_apod + a forward FFT2 of the grid (torch.fft.fft2 convention);
+ *   nufft_inv_grid == an unnormalised inverse FFT2 of the grid + nufft_crop_apod.
+ * work_c64: caller-owned scratch of nframes * R * G complex64 (any contents). */
+int nufft_grid_fft_supported(int R, int G);
+int nufft_fwd_grid(const float* x, int nframes, int T, const nufft_plan_t* plan, float* work_c64,
+                   float* grid_c64, void* stream);
+int nufft_inv_grid(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                   const float* chain_scale, float out_scale, float* work_c64, float* out,
+                   void* stream);
+
 /* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in
  * the reference.  Same arguments, kernels and results as mri_loss_grad(variant = 0); the

@@ -106,6 +106,9 @@ SIGNATURES = {
     "nufft_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     "nufft_spread": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
     "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
+    "nufft_grid_fft_supported": (c_i, [c_i, c_i]),
+    "nufft_fwd_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p, c_p]),
+    "nufft_inv_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                    c_p, c_p]),
     "mcmc_update_philox": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, C.POINTER(mcmc_params_t), c_p, c_i64,

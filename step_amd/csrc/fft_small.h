@@ -1,5 +1,5 @@
-// In-register small FFTs (3, 4, 12, 16 points) and the 192 = 16 x 12 decomposition used by
-// the fused MRI kernels.  Plain C++ so that the same code is unit-tested on the host
+// In-register small FFTs (3, 4, 12, 16, 24 points), the 192 = 16 x 12 decomposition used by
+// the fused MRI kernels and the 384 = 16 x 24 one of the radial-MRI grid transforms.  Plain C++ so that the same code is unit-tested on the host
 // (tests/test_fft_small_host.py compiles it with g++ against a naive DFT).
 //
 // SIGN = -1: forward transform  X[k] = sum_n x[n] exp(-2 pi i n k / N)   (torch.fft.fftn)
@@ -120,3 +120,44 @@ FFT_HD void fft192_pass_a(cf32 (&v)[16], int b, const cf32* tw) {
 }
 template <int SIGN>
 FFT_HD void fft192_pass_b(cf32 (&v)[12]) { fft12<SIGN>(v); }
+
+// 24-point FFT, natural order in and out: radix 2 over two 12-point transforms
+// (X[d] = E[d] + W24^d O[d], X[d + 12] = E[d] - W24^d O[d]).
+template <int SIGN>
+FFT_HD void fft24(cf32 (&v)[24]) {
+    // (cos, sin)(2 pi d / 24), d < 12
+    const float C24[12] = {1.f, 0.96592582628906829f, 0.86602540378443865f, 0.70710678118654752f, 0.5f,
+                           0.25881904510252076f, 0.f, -0.25881904510252076f, -0.5f, -0.70710678118654752f,
+                           -0.86602540378443865f, -0.96592582628906829f};
+    const float S24[12] = {0.f, 0.25881904510252076f, 0.5f, 0.70710678118654752f, 0.86602540378443865f,
+                           0.96592582628906829f, 1.f, 0.96592582628906829f, 0.86602540378443865f,
+                           0.70710678118654752f, 0.5f, 0.25881904510252076f};
+    cf32 e[12], o[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { e[j] = v[2 * j]; o[j] = v[2 * j + 1]; }
+    fft12<SIGN>(e);
+    fft12<SIGN>(o);
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+        const cf32 t = c_rot<SIGN>(o[d], C24[d], S24[d]);
+        v[d] = c_add(e[d], t);
+        v[d + 12] = c_sub(e[d], t);
+    }
+}
+
+// 384-point FFT as 16 x 24 (n = 24 a + b, k = c + 16 d), the oversampled grid of the radial-MRI
+// NUFFT (nufft_fft.hip):
+//   pass A, task b (0..23):  Y_b[c] = W384^(b c) * FFT16_a( x[24 a + b] ),  stored at slot 24 c + b
+//   pass B, task c (0..15):  X[c + 16 d] = FFT24_b( Y_b[c] ),  read from slots 24 c + b
+// tw[m] = (cos, sin)(2 pi m / 384), m < 384 (b c <= 23 * 15 = 345).
+template <int SIGN>
+FFT_HD void fft384_pass_a(cf32 (&v)[16], int b, const cf32* tw) {
+    fft16<SIGN>(v);
+#pragma unroll
+    for (int c = 1; c < 16; ++c) {
+        const cf32 w = tw[b * c];
+        v[c] = c_rot<SIGN>(v[c], w.x, w.y);
+    }
+}
+template <int SIGN>
+FFT_HD void fft384_pass_b(cf32 (&v)[24]) { fft24<SIGN>(v); }

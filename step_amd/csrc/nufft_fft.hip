@@ -1,0 +1,226 @@
+// The oversampled-grid transforms of the radial-MRI NUFFT (nufft_grid.hip) for R = 192, G = 384,
+// fused with the padding / cropping and the de-apodisation and pruned to what is not zero.
+// NO REFERENCE COUNTERPART (see nufft_grid.hip).
+//
+// A library FFT2 of the zero-padded grid moves every frame's 1.18 MB grid through HBM four times
+// (pad, two transposed passes each way) and copies it once more; three quarters of what it
+// transforms is zero (forward) or thrown away (adjoint).  Here each direction is two passes:
+//
+//   forward:  image rows    --pad + deapodise, FFT_384 along x-->  T [R][G]   (only the R rows that exist)
+//             T columns     --FFT_384 along y over the R non-zero rows-->      grid [G][G]
+//   adjoint:  grid columns  --IFFT_384 along y, only the R rows kept-->        T [R][G]
+//             T rows        --IFFT_384 along x, crop + deapodise-->            image rows
+//
+// per frame 295 KB + 2 x 590 KB + 1.18 MB each way instead of ~8 x 1.18 MB.  384 = 16 x 24
+// (fft_small.h: fft384_pass_a / fft384_pass_b, unit-tested on the host); pixel n of an axis sits at
+// grid index (n - R/2) mod G, so of the 16 inputs 24 a + b of a pass-A task exactly a < 4 and
+// a >= 12 are image samples, and of the 24 outputs c + 16 d of a pass-B task exactly d < 6 and
+// d >= 18 are image rows.  Column passes: 32 columns per workgroup, tasks laid out column-fastest
+// so that every global access is a 256-byte row segment and the LDS exchange is conflict-free;
+// row passes: 16 rows per workgroup through one LDS tile, loads and stores as whole rows.
+#include "common.h"
+#include "fft_small.h"
+
+#define NF_R 192
+#define NF_G 384
+#define NF_H 96
+#define NF_CW 32             // columns per workgroup (column passes)
+#define NF_CT 768            // threads: 24 pass-A tasks x 32 columns
+#define NF_RW 16             // rows per workgroup (row passes)
+#define NF_RT 384            // threads: 24 pass-A tasks x 16 rows
+#define NF_RS 400            // LDS row stride of the row passes (slots 25 c + b <= 398)
+
+__device__ __forceinline__ void nf_twiddles(cf32* tw, int tid, int nthreads) {
+    for (int m = tid; m < NF_G; m += nthreads) {
+        float sn, cs;
+        sincospif((float)m * (1.0f / 192.0f), &sn, &cs);      // 2 pi m / 384
+        tw[m] = c_make(cs, sn);
+    }
+}
+
+// SIGN = -1: in = T [f][R][G] (image rows), out = grid [f][G][G]
+// SIGN = +1: in = grid [f][G][G], out = T [f][R][G] (image rows), unnormalised
+template <int SIGN>
+__global__ __launch_bounds__(NF_CT) void k_nufft_fft_cols(const cf32* __restrict__ in, cf32* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) cf32 nf_lds[];
+    cf32* tw = nf_lds;                                        // [384]
+    cf32* E = nf_lds + NF_G;                                  // [384 slots][32 columns]
+    const int tid = threadIdx.x, col = tid & (NF_CW - 1), q = tid / NF_CW;
+    const int f = blockIdx.y, kx = blockIdx.x * NF_CW + col;
+    cf32 v[16];
+    {
+        const int b = q;                                      // pass-A task: grid rows 24 a + b
+        if (SIGN < 0) {
+            const cf32* src = in + (size_t)f * NF_R * NF_G + kx;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int n = 24 * a + b;                     // a < 4: pixel row n + 96, a >= 12: n - 288
+                v[a] = a < 4 ? src[(size_t)(n + NF_H) * NF_G]
+                             : (a >= 12 ? src[(size_t)(n - (NF_G - NF_H)) * NF_G] : c_make(0.f, 0.f));
+            }
+        } else {
+            const cf32* src = in + (size_t)f * NF_G * NF_G + kx;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = src[(size_t)(24 * a + b) * NF_G];
+        }
+        nf_twiddles(tw, tid, NF_CT);
+        __syncthreads();
+        fft384_pass_a<SIGN>(v, b, tw);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) E[(24 * c + b) * NF_CW + col] = v[c];
+    }
+    __syncthreads();
+    if (q < 16) {
+        const int c = q;                                      // pass-B task: grid rows c + 16 d
+        cf32 u[24];
+#pragma unroll
+        for (int b = 0; b < 24; ++b) u[b] = E[(24 * c + b) * NF_CW + col];
+        fft384_pass_b<SIGN>(u);
+        if (SIGN < 0) {
+            cf32* dst = out + (size_t)f * NF_G * NF_G + kx;
+#pragma unroll
+            for (int d = 0; d < 24; ++d) dst[(size_t)(c + 16 * d) * NF_G] = u[d];
+        } else {
+            cf32* dst = out + (size_t)f * NF_R * NF_G + kx;
+#pragma unroll
+            for (int d = 0; d < 24; ++d) {
+                const int k = c + 16 * d;                     // d < 6: pixel row k + 96, d >= 18: k - 288
+                if (d < 6) dst[(size_t)(k + NF_H) * NF_G] = u[d];
+                else if (d >= 18) dst[(size_t)(k - (NF_G - NF_H)) * NF_G] = u[d];
+            }
+        }
+    }
+}
+
+// The two passes of NF_RW rows held in one LDS tile (row stride NF_RS): in place, natural order.
+// PRUNED_IN: only grid indices < 96 and >= 288 of a row hold data (the rest is taken as zero and
+// need not be initialised).
+template <int SIGN, bool PRUNED_IN>
+__device__ __forceinline__ void nf_rows_in_lds(cf32* buf, const cf32* tw, int tid) {
+    cf32 v[16];
+    const int row = tid / 24, b = tid - row * 24;
+    cf32* r = buf + row * NF_RS;
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        v[a] = (!PRUNED_IN || a < 4 || a >= 12) ? r[24 * a + b] : c_make(0.f, 0.f);
+    fft384_pass_a<SIGN>(v, b, tw);
+    __syncthreads();                                          // every input has been read
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r[25 * c + b] = v[c];       // slot stride 25: pass B reads conflict-free
+    __syncthreads();
+    cf32 u[24];
+    const int row2 = tid / 16, c2 = tid - row2 * 16;
+    cf32* r2 = buf + row2 * NF_RS;
+    if (tid < NF_RW * 16) {
+#pragma unroll
+        for (int bb = 0; bb < 24; ++bb) u[bb] = r2[25 * c2 + bb];
+        fft384_pass_b<SIGN>(u);
+    }
+    __syncthreads();                                          // every slot has been read
+    if (tid < NF_RW * 16) {
+#pragma unroll
+        for (int d = 0; d < 24; ++d) r2[c2 + 16 * d] = u[d];
+    }
+    __syncthreads();
+}
+
+// T[f][y][kx] = FFT_384 over gx of (apod[y] apod[x] (x_re + i x_im)[y][x] placed at gx = (x - R/2) mod G)
+__global__ __launch_bounds__(NF_RT) void k_nufft_rows_fwd(const float* __restrict__ x, const float* __restrict__ apod,
+                                                          cf32* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) cf32 nf_lds[];
+    cf32* tw = nf_lds;
+    cf32* buf = nf_lds + NF_G;
+    const int tid = threadIdx.x, f = blockIdx.y, y0 = blockIdx.x * NF_RW;
+    const float* xr = x + (size_t)f * 2 * NF_R * NF_R;
+    const float* xi = xr + (size_t)NF_R * NF_R;
+    nf_twiddles(tw, tid, NF_RT);
+    for (int i = tid; i < NF_RW * NF_R; i += NF_RT) {
+        const int row = i / NF_R, n = i - row * NF_R, y = y0 + row;
+        const float a = apod[y] * apod[n];
+        const int g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
+        buf[row * NF_RS + g] = c_make(a * xr[y * NF_R + n], a * xi[y * NF_R + n]);
+    }
+    __syncthreads();
+    nf_rows_in_lds<-1, true>(buf, tw, tid);
+    cf32* dst = T + ((size_t)f * NF_R + y0) * NF_G;
+    for (int i = tid; i < NF_RW * NF_G; i += NF_RT) {
+        const int row = i / NF_G, k = i - row * NF_G;
+        dst[(size_t)row * NF_G + k] = buf[row * NF_RS + k];
+    }
+}
+
+// out[f][0/1][y][x] = scale * apod[y] apod[x] * Re/Im IFFT_384(T[f][y][:]) at gx = (x - R/2) mod G
+__global__ __launch_bounds__(NF_RT) void k_nufft_rows_inv(const cf32* __restrict__ T, const float* __restrict__ apod,
+                                                          int frames_per_chain, const float* __restrict__ chain_scale,
+                                                          float out_scale, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) cf32 nf_lds[];
+    cf32* tw = nf_lds;
+    cf32* buf = nf_lds + NF_G;
+    const int tid = threadIdx.x, f = blockIdx.y, y0 = blockIdx.x * NF_RW;
+    const float cs = out_scale * (chain_scale ? chain_scale[f / frames_per_chain] : 1.f);
+    nf_twiddles(tw, tid, NF_RT);
+    const cf32* src = T + ((size_t)f * NF_R + y0) * NF_G;
+    for (int i = tid; i < NF_RW * NF_G; i += NF_RT) {
+        const int row = i / NF_G, k = i - row * NF_G;
+        buf[row * NF_RS + k] = src[(size_t)row * NF_G + k];
+    }
+    __syncthreads();
+    nf_rows_in_lds<1, false>(buf, tw, tid);
+    float* outr = out + (size_t)f * 2 * NF_R * NF_R;
+    float* outi = outr + (size_t)NF_R * NF_R;
+    for (int i = tid; i < NF_RW * NF_R; i += NF_RT) {
+        const int row = i / NF_R, n = i - row * NF_R, y = y0 + row;
+        const float a = cs * apod[y] * apod[n];
+        const int g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
+        const cf32 v = buf[row * NF_RS + g];
+        outr[y * NF_R + n] = a * v.x;
+        outi[y * NF_R + n] = a * v.y;
+    }
+}
+
+static const size_t NF_LDS_COLS = (size_t)(NF_G + NF_G * NF_CW) * sizeof(cf32);
+static const size_t NF_LDS_ROWS = (size_t)(NF_G + NF_RW * NF_RS) * sizeof(cf32);
+
+static int nf_check(const char* who, const nufft_plan_t* p, int nframes, int T) {
+    STEP_REQUIRE(p && p->apod, "%s: null plan", who);
+    STEP_REQUIRE(p->R == NF_R && p->G == NF_G, "%s: built for R = %d, G = %d (got R = %d, G = %d)", who, NF_R, NF_G,
+                 p->R, p->G);
+    STEP_REQUIRE(nframes > 0 && nframes <= 65535 && T > 0 && nframes % T == 0, "%s: %d frames (1..65535), T = %d", who,
+                 nframes, T);
+    return STEP_OK;
+}
+
+extern "C" int nufft_grid_fft_supported(int R, int G) { return R == NF_R && G == NF_G; }
+
+extern "C" int nufft_fwd_grid(const float* x, int nframes, int T, const nufft_plan_t* plan, float* work_c64,
+                              float* grid_c64, void* stream) {
+    STEP_REQUIRE(x && work_c64 && grid_c64, "nufft_fwd_grid: null pointer");
+    if (int rc = nf_check("nufft_fwd_grid", plan, nframes, T)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    step_allow_lds((const void*)k_nufft_rows_fwd, NF_LDS_ROWS);
+    hipLaunchKernelGGL(k_nufft_rows_fwd, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st, x, plan->apod,
+                       (cf32*)work_c64);
+    STEP_CHECK_LAUNCH("nufft_fwd_grid (rows)");
+    step_allow_lds((const void*)k_nufft_fft_cols<-1>, NF_LDS_COLS);
+    hipLaunchKernelGGL((k_nufft_fft_cols<-1>), dim3(NF_G / NF_CW, nframes), dim3(NF_CT), NF_LDS_COLS, st,
+                       (const cf32*)work_c64, (cf32*)grid_c64);
+    STEP_CHECK_LAUNCH("nufft_fwd_grid (columns)");
+    return STEP_OK;
+}
+
+extern "C" int nufft_inv_grid(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                              const float* chain_scale, float out_scale, float* work_c64, float* out,
+                              void* stream) {
+    STEP_REQUIRE(grid_c64 && work_c64 && out, "nufft_inv_grid: null pointer");
+    if (int rc = nf_check("nufft_inv_grid", plan, nframes, T)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    step_allow_lds((const void*)k_nufft_fft_cols<1>, NF_LDS_COLS);
+    hipLaunchKernelGGL((k_nufft_fft_cols<1>), dim3(NF_G / NF_CW, nframes), dim3(NF_CT), NF_LDS_COLS, st,
+                       (const cf32*)grid_c64, (cf32*)work_c64);
+    STEP_CHECK_LAUNCH("nufft_inv_grid (columns)");
+    step_allow_lds((const void*)k_nufft_rows_inv, NF_LDS_ROWS);
+    hipLaunchKernelGGL(k_nufft_rows_inv, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st,
+                       (const cf32*)work_c64, plan->apod, T, chain_scale, out_scale, out);
+    STEP_CHECK_LAUNCH("nufft_inv_grid (rows)");
+    return STEP_OK;
+}

@@ -132,6 +132,7 @@ class RadialMRI(Operator):
         self._host = kb_plan(kappa, resolution, kernel_width)
         self.J = self._host["J"]
         self.max_chunk = max_chunk        # chains per pass: the oversampled grids are 8 G^2 bytes per frame
+        self.grid_fft = 'auto'            # 'auto' | 'fused' (nufft_fft.hip) | 'library' (torch.fft around pad / crop)
         self._dev = {}
 
     _prof = None
@@ -154,10 +155,22 @@ class RadialMRI(Operator):
             raise ValueError("mri_radial expects [B, %d, 2, %d, %d], got %s" % (self.frames, R, R, tuple(x.shape)))
         return x.to(torch.float32).contiguous()
 
+    def _own_fft(self):
+        """The fused, pruned grid transforms (nufft_fft.hip) exist for R = 192; other sizes take
+        pad / crop kernels around a library FFT2."""
+        return self.grid_fft == 'fused' or (self.grid_fft == 'auto'
+                                            and bool(_lib.lib().nufft_grid_fft_supported(self.resolution, 2 * self.resolution)))
+
     def _grid_fft(self, x):
         """pad + de-apodise -> FFT2 on the oversampled grid: [B, T, G, G] complex64."""
-        B, T, G = x.shape[0], self.frames, 2 * self.resolution
+        B, T, R, G = x.shape[0], self.frames, self.resolution, 2 * self.resolution
         grid = torch.empty(B, T, G, G, device=x.device, dtype=torch.complex64)
+        if self._own_fft():
+            work = torch.empty(B, T, R, G, device=x.device, dtype=torch.complex64)
+            rc = _lib.lib().nufft_fwd_grid(x.data_ptr(), B * T, T, C.byref(self._plan(x.device)), work.data_ptr(),
+                                           grid.data_ptr(), _lib.stream_of(x))
+            _lib.check(rc, "nufft_fwd_grid")
+            return grid
         rc = _lib.lib().nufft_pad_apod(x.data_ptr(), B * T, T, C.byref(self._plan(x.device)), grid.data_ptr(),
                                        _lib.stream_of(x))
         _lib.check(rc, "nufft_pad_apod")
@@ -191,8 +204,13 @@ class RadialMRI(Operator):
             n = vc.shape[0]
             grid = torch.empty(n, T, G, G, device=vals.device, dtype=torch.complex64)
             _lib.check(L.nufft_spread(vc.data_ptr(), n * T, T, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
-            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse (in place measured slower)
             cs = None if chain_scale is None else chain_scale[i:i + n].contiguous()
+            if self._own_fft():
+                work = torch.empty(n, T, R, G, device=vals.device, dtype=torch.complex64)
+                _lib.check(L.nufft_inv_grid(grid.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
+                                            work.data_ptr(), out[i:i + n].data_ptr(), st), "nufft_inv_grid")
+                continue
+            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse (in place measured slower)
             _lib.check(L.nufft_crop_apod(Z.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
                                          out[i:i + n].data_ptr(), st), "nufft_crop_apod")
         return out

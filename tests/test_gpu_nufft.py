@@ -16,14 +16,16 @@ def make(**kw):
     return get_operator("mri_radial", **kw)
 
 
+@pytest.mark.parametrize("grid_fft", ["fused", "library"])
 @pytest.mark.parametrize("spokes,frames,shared", [(32, 12, False), (13, 3, True)])
-def test_matches_direct_nudft(spokes, frames, shared, dev):
+def test_matches_direct_nudft(spokes, frames, shared, grid_fft, dev):
     from step_amd.forward_operator import golden_angle_radial
     traj = golden_angle_radial(1 if shared else frames, spokes, 192)
     if shared:                                              # an arbitrary (non-radial) set as well
         rng = np.random.RandomState(0)
         traj = np.concatenate([traj, rng.uniform(-96, 96, (1, 500, 2))], axis=1)
     op, orc = make(spokes=spokes, frames=frames, trajectory=traj), NUDFTOracle(traj, 192)
+    op.grid_fft = grid_fft              # nufft_fft.hip's pruned passes / pad + torch.fft + crop
     gen = torch.Generator().manual_seed(spokes)
     x = torch.randn(2, frames, 2, 192, 192, generator=gen)
     y = orc(torch.randn(2, frames, 2, 192, 192, generator=gen)).float() + 0.1 * torch.randn(2, frames, op.J, 2, generator=gen)
@@ -70,3 +72,34 @@ def test_radial_langevin_step_runs_in_the_sampler(dev):
     l0 = op.loss(x0, y)
     out = s.optimize(x0, op, y, 10.0, 0.0)
     assert torch.isfinite(out).all() and (op.loss(out, y) < l0).all()
+
+
+def test_fused_grid_transforms_equal_pad_fft_crop(dev):
+    """nufft_fwd_grid == nufft_pad_apod + fft2 and nufft_inv_grid == unnormalised ifft2 +
+    nufft_crop_apod on the whole grid (not only where samples look), to fp32 FFT rounding."""
+    op = make(spokes=8, frames=12)
+    assert op._own_fft()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
+    op.grid_fft = "fused"
+    a = op._grid_fft(x)
+    op.grid_fft = "library"
+    b = op._grid_fft(x)
+    assert_close(torch.view_as_real(a), torch.view_as_real(b), 2e-6, "forward grid")
+    # adjoint half on an arbitrary grid: reach it through _type1's second half
+    from step_amd import _lib
+    import ctypes as C
+    grid = torch.randn(3, 12, 384, 384, 2, device=dev, generator=gen)
+    cs = torch.tensor([0.5, -1.0, 2.0], device=dev)
+    plan, st = op._plan(x.device), _lib.stream_of(x)
+    out_f = torch.empty_like(x)
+    work = torch.empty(3, 12, 192, 384, 2, device=dev)
+    _lib.check(_lib.lib().nufft_inv_grid(grid.data_ptr(), 36, 12, C.byref(plan), cs.data_ptr(), 0.25, work.data_ptr(),
+                                         out_f.data_ptr(), st), "nufft_inv_grid")
+    Z = torch.fft.ifft2(torch.view_as_complex(grid), norm="forward")
+    out_l = torch.empty_like(x)
+    _lib.check(_lib.lib().nufft_crop_apod(Z.data_ptr(), 36, 12, C.byref(plan), cs.data_ptr(), 0.25, out_l.data_ptr(), st),
+               "nufft_crop_apod")
+    assert_close(out_f, out_l, 2e-6, "adjoint image")
+    rc = _lib.lib().nufft_fwd_grid(x.data_ptr(), 36, 5, C.byref(plan), work.data_ptr(), a.data_ptr(), st)
+    assert rc != 0 and b"frames" in _lib.lib().step_last_error()
