@@ -45,7 +45,8 @@ class bh_step_ws_t(C.Structure):
 class nufft_plan_t(C.Structure):
     _fields_ = [("R", C.c_int32), ("G", C.c_int32), ("W", C.c_int32), ("J", C.c_int32), ("traj_frames", C.c_int32),
                 ("ix0", c_p), ("iy0", c_p), ("wx", c_p), ("wy", c_p), ("tile_ptr", c_p), ("tile_ent", c_p),
-                ("tile_base", c_p), ("apod", c_p)]
+                ("tile_base", c_p), ("apod", c_p), ("own_ptr", c_p), ("own_ent", c_p),
+                ("own_x0", c_p), ("own_y0", c_p), ("own_wx", c_p), ("own_wy", c_p)]
 
 
 class mcmc_params_t(C.Structure):
@@ -107,6 +108,7 @@ SIGNATURES = {
     "nufft_spread": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
     "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
     "nufft_grid_fft_supported": (c_i, [c_i, c_i]),
+    "nufft_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
     "nufft_fwd_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p, c_p]),
     "nufft_inv_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,

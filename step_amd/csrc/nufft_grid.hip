@@ -34,6 +34,12 @@ struct NuPlan {
     const int32_t* tile_ent;                  // [traj_frames][...] sample ids, ascending per tile
     const int64_t* tile_base;                 // [traj_frames] offset of a trajectory frame's entries in tile_ent
     const float* apod;                        // [R] 1 / kernel transform at pixel n (per axis)
+    const int32_t* own_ptr;                   // [traj_frames][(G/32)^2 + 1] samples by the 32 x 32 tile that holds
+    const int32_t* own_ent;                   // [traj_frames][J]            their footprint's first point, or null;
+    const int32_t* own_x0;                    // [traj_frames][J] first point (wrapped into [0, G)) and weights
+    const int32_t* own_y0;                    //                  in the order of own_ent
+    const float* own_wx;                      // [traj_frames][J][W]
+    const float* own_wy;
 };
 
 __device__ __forceinline__ int nu_wrap(int i, int G) { return i < 0 ? i + G : (i >= G ? i - G : i); }
@@ -111,6 +117,116 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
     if (loss_part) {
         const float tot = block_sum(acc, red);
         if (threadIdx.x == 0) loss_part[(size_t)f * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+// The same interpolation with the grid staged through LDS: a workgroup owns a 32 x 32 tile of
+// frame index t for NI_CH chains, loads the tile plus the W - 1 rows / columns a footprint that
+// starts in it can reach (each grid point crosses HBM about 1.3 times instead of being gathered
+// 36 times through L2), then takes the samples whose footprint starts in the tile: the host has
+// binned them (every sample in exactly one tile) and laid their tables out in bin order, so a
+// thread reads its sample's first point and 2 W weights from consecutive memory -- no dependent
+// gathers, no staging, no barrier per batch of samples.  One (sample, chain) pair per thread at a
+// time, the 36 products from LDS in the order of k_nufft_interp.
+// loss_part[f][tile] = the tile's share of sum |yhat - y|^2.
+#define NI_TILE 32
+#define NI_CH 4
+#define NI_SPAN (NI_TILE + NU_WMAX - 1)
+__global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __restrict__ grid, NuPlan p, int T, int B,
+                                                            const float2* __restrict__ y, int y_batch,
+                                                            float res_scale, float2* __restrict__ out,
+                                                            float* __restrict__ loss_part) {
+    __shared__ float2 s_g[NI_CH][NI_SPAN * NI_SPAN];
+    __shared__ float red[256];
+    const int G = p.G, W = p.W, nt = G / NI_TILE, ntiles = nt * nt, span = NI_TILE + W - 1;
+    const int tile = blockIdx.x, ty = tile / nt, tx = tile - ty * nt;
+    const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * NI_CH, tf = p.traj_frames == 1 ? 0 : t;
+    const int nc = min(NI_CH, B - b0), tid = threadIdx.x;
+    const int32_t* ptr = p.own_ptr + (size_t)tf * (ntiles + 1);
+    const int e0 = ptr[tile], e1 = ptr[tile + 1];
+    if (e0 == e1) {                                           // nothing starts here (uniform)
+        if (loss_part && tid < nc) loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = 0.f;
+        return;
+    }
+    {
+        // a 64-lane group per grid row (span <= 39 lanes load), four rows per pass, eight passes in
+        // flight: the loads of a pass do not wait for the LDS stores of the one before
+        const int lane = tid & 63, rq = tid >> 6, nrows = nc * span;
+        const int gx = nu_wrap(tx * NI_TILE + lane, G);
+        for (int r0 = rq; r0 < nrows; r0 += 32) {
+            float2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + 4 * i;
+                v[i] = make_float2(0.f, 0.f);
+                if (r < nrows && lane < span) {
+                    const int c = r / span, ry = r - c * span;
+                    const int gy = nu_wrap(ty * NI_TILE + ry, G);
+                    v[i] = grid[((size_t)(b0 + c) * T + t) * G * G + (size_t)gy * G + gx];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + 4 * i;
+                if (r < nrows && lane < span) {
+                    const int c = r / span, ry = r - c * span;
+                    s_g[c][ry * span + lane] = v[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int q = tid >> 2, c = tid & 3;                      // this thread's sample slot and chain
+    const size_t tb = (size_t)tf * p.J;
+    float acc = 0.f;
+    if (c < nc) {
+        const int b = b0 + c;
+        for (int s = e0 + q; s < e1; s += 64) {
+            const int j = p.own_ent[tb + s];
+            const int lx = p.own_x0[tb + s] - tx * NI_TILE, ly = p.own_y0[tb + s] - ty * NI_TILE;
+            const float* wxp = p.own_wx + (tb + s) * W;
+            const float* wyp = p.own_wy + (tb + s) * W;
+            float wxr[NU_WMAX], wyr[NU_WMAX];
+#pragma unroll
+            for (int k = 0; k < NU_WMAX; ++k) {
+                wxr[k] = k < W ? wxp[k] : 0.f;
+                wyr[k] = k < W ? wyp[k] : 0.f;
+            }
+            const float2* g0 = s_g[c] + ly * span + lx;
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int a = 0; a < NU_WMAX; ++a)
+                if (a < W) {
+                    const float2* row = g0 + a * span;
+                    float rr = 0.f, ri = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NU_WMAX; ++k)
+                        if (k < W) {
+                            const float2 v = row[k];
+                            rr += wxr[k] * v.x;
+                            ri += wxr[k] * v.y;
+                        }
+                    sr += wyr[a] * rr;
+                    si += wyr[a] * ri;
+                }
+            float2 o = make_float2(sr, si);
+            if (y) {
+                const float2 m = y[((size_t)(y_batch > 1 ? b : 0) * T + t) * p.J + j];
+                const float dr = sr - m.x, di = si - m.y;
+                acc += dr * dr + di * di;
+                o = make_float2(res_scale * dr, res_scale * di);
+            }
+            out[((size_t)b * T + t) * p.J + j] = o;
+        }
+    }
+    if (loss_part) {
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < nc) {                                       // thread c: its chain's 64 partials, in order
+            float s = 0.f;
+            for (int i = 0; i < 64; ++i) s += red[4 * i + tid];
+            loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = s;
+        }
     }
 }
 
@@ -196,26 +312,30 @@ __global__ __launch_bounds__(256) void k_nufft_crop_apod(const float2* __restric
     }
 }
 
-// loss[b] = sum of the chain's partials in a fixed order; total = sum_b loss[b]
-__global__ __launch_bounds__(256) void k_nufft_loss_finish(const float* __restrict__ part, int per_chain, int B,
-                                                           float* __restrict__ loss, float* __restrict__ total) {
+// loss[b] = sum of the chain's partials: a workgroup per chain, thread i adds entries i, i + 256, ...
+// in order and the 256 sums are folded by a fixed tree; k_nufft_loss_total adds the chains in order.
+__global__ __launch_bounds__(256) void k_nufft_loss_finish(const float* __restrict__ part, int per_chain,
+                                                           float* __restrict__ loss) {
     __shared__ float red[256];
-    const int tid = threadIdx.x;
-    float mine = 0.f;
-    for (int b = tid; b < B; b += 256) {
-        const float* q = part + (size_t)b * per_chain;
-        float s = 0.f;
-        for (int i = 0; i < per_chain; ++i) s += q[i];
-        loss[b] = s;
-        mine += s;
-    }
-    red[tid] = mine;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float* q = part + (size_t)b * per_chain;
+    float s = 0.f;
+    for (int i = tid; i < per_chain; i += 256) s += q[i];
+    red[tid] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if (tid < w) red[tid] += red[tid + w];
         __syncthreads();
     }
-    if (total && tid == 0) *total = red[0];
+    if (tid == 0) loss[b] = red[0];
+}
+
+__global__ void k_nufft_loss_total(const float* __restrict__ loss, int B, float* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += loss[b];
+        *total = s;
+    }
 }
 
 static int nu_check(const char* who, const nufft_plan_t* p, int nframes, int T) {
@@ -232,7 +352,8 @@ static int nu_check(const char* who, const nufft_plan_t* p, int nframes, int T) 
 
 static NuPlan nu_plan(const nufft_plan_t* p) {
     return NuPlan{p->R, p->G, p->W, p->J, p->traj_frames, p->G / NU_TILE, p->ix0, p->iy0, p->wx, p->wy,
-                  p->tile_ptr, p->tile_ent, p->tile_base, p->apod};
+                  p->tile_ptr, p->tile_ent, p->tile_base, p->apod, p->own_ptr, p->own_ent, p->own_x0, p->own_y0,
+                  p->own_wx, p->own_wy};
 }
 
 extern "C" int nufft_interp_blocks(int J) { return (J + 255) / 256; }
@@ -247,6 +368,16 @@ extern "C" int nufft_pad_apod(const float* x, int nframes, int T, const nufft_pl
     return STEP_OK;
 }
 
+// the tiled kernel needs the owner bins and whole 32 x 32 tiles
+static bool nu_tiled(const nufft_plan_t* p) {
+    return p->own_ptr && p->own_ent && p->own_x0 && p->own_y0 && p->own_wx && p->own_wy && p->G % NI_TILE == 0;
+}
+
+extern "C" int nufft_interp_parts(const nufft_plan_t* plan) {
+    if (!plan) return 0;
+    return nu_tiled(plan) ? (plan->G / NI_TILE) * (plan->G / NI_TILE) : nufft_interp_blocks(plan->J);
+}
+
 extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
                             const float* y_c64, int y_batch, float res_scale, float* out_c64,
                             float* loss_part, float* loss, float* loss_total, void* stream) {
@@ -255,14 +386,23 @@ extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nuf
     const int B = nframes / T;
     STEP_REQUIRE(!y_c64 || y_batch == 1 || y_batch == B, "nufft_interp: measurement batch %d vs B=%d", y_batch, B);
     STEP_REQUIRE(!loss || (y_c64 && loss_part), "nufft_interp: the loss needs the measurement and loss_part");
-    const int nblk = nufft_interp_blocks(plan->J);
-    hipLaunchKernelGGL(k_nufft_interp, dim3(nblk, nframes), dim3(256), 0, (hipStream_t)stream,
-                       (const float2*)grid_c64, nu_plan(plan), T, (const float2*)y_c64, y_batch, res_scale,
-                       (float2*)out_c64, y_c64 ? loss_part : nullptr);
+    STEP_REQUIRE(!loss_total || loss, "nufft_interp: loss_total needs loss");
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = nufft_interp_parts(plan);
+    if (nu_tiled(plan)) {
+        STEP_REQUIRE(T * ((B + NI_CH - 1) / NI_CH) <= 65535, "nufft_interp: %d chains x %d frames exceed the grid", B, T);
+        hipLaunchKernelGGL(k_nufft_interp_tiled, dim3(parts, T * ((B + NI_CH - 1) / NI_CH)), dim3(256), 0, st,
+                           (const float2*)grid_c64, nu_plan(plan), T, B, (const float2*)y_c64, y_batch, res_scale,
+                           (float2*)out_c64, y_c64 ? loss_part : nullptr);
+    } else {
+        hipLaunchKernelGGL(k_nufft_interp, dim3(parts, nframes), dim3(256), 0, st, (const float2*)grid_c64,
+                           nu_plan(plan), T, (const float2*)y_c64, y_batch, res_scale, (float2*)out_c64,
+                           y_c64 ? loss_part : nullptr);
+    }
     STEP_CHECK_LAUNCH("nufft_interp");
     if (loss) {
-        hipLaunchKernelGGL(k_nufft_loss_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_part, T * nblk, B,
-                           loss, loss_total);
+        hipLaunchKernelGGL(k_nufft_loss_finish, dim3(B), dim3(256), 0, st, loss_part, T * parts, loss);
+        if (loss_total) hipLaunchKernelGGL(k_nufft_loss_total, dim3(1), dim3(64), 0, st, loss, B, loss_total);
         STEP_CHECK_LAUNCH("nufft_interp (loss)");
     }
     return STEP_OK;

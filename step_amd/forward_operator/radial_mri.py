@@ -27,6 +27,7 @@ from .base import Operator, register_operator
 __all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
 
 _TILE = 16
+_OWN_TILE = 32                      # tile of the interpolation kernel (NI_TILE in nufft_grid.hip)
 
 
 def golden_angle_radial(frames, spokes, resolution):
@@ -74,6 +75,20 @@ def kb_plan(kappa, R, W=6):
         ptrs.append(ptr)
         ents.append(np.array([j for l in lists for j in l], dtype=np.int32))
         base.append(base[-1] + len(ents[-1]))
+    # every sample once, by the 32 x 32 tile in which its footprint starts (the interpolation kernel
+    # stages that tile and the W - 1 points beyond it in LDS); needs whole tiles
+    own_ptr = own_ent = own_x0 = own_y0 = own_wx = own_wy = None
+    if G % _OWN_TILE == 0:
+        no = G // _OWN_TILE
+        key = ((i0[..., 1] % G) // _OWN_TILE) * no + (i0[..., 0] % G) // _OWN_TILE        # [Tt, J]
+        own_ent = np.argsort(key, axis=1, kind="stable").astype(np.int32)
+        own_ptr = np.zeros((Tt, no * no + 1), np.int32)
+        for t in range(Tt):
+            own_ptr[t, 1:] = np.cumsum(np.bincount(key[t], minlength=no * no))
+        # the tables once more in bin order: the kernel reads a tile's samples from consecutive memory
+        take = lambda a: np.take_along_axis(a, own_ent.astype(np.int64).reshape(own_ent.shape + (1,) * (a.ndim - 2)), axis=1)
+        own_x0, own_y0 = take((i0[..., 0] % G).astype(np.int32)), take((i0[..., 1] % G).astype(np.int32))
+        own_wx, own_wy = take(w[:, :, 0].astype(np.float32)), take(w[:, :, 1].astype(np.float32))
     # continuous transform of the kernel at nu = (n - R/2) / G cycles per grid sample
     d = np.linspace(-W / 2.0, W / 2.0, 4001)
     nu = (np.arange(R) - R / 2) / G
@@ -82,7 +97,8 @@ def kb_plan(kappa, R, W=6):
                 ix0=i0[..., 0].astype(np.int32), iy0=i0[..., 1].astype(np.int32),
                 wx=w[:, :, 0].astype(np.float32), wy=w[:, :, 1].astype(np.float32),
                 tile_ptr=np.stack(ptrs), tile_ent=np.concatenate(ents), tile_base=np.array(base[:-1], np.int64),
-                apod=(1.0 / phat).astype(np.float32))
+                apod=(1.0 / phat).astype(np.float32), own_ptr=own_ptr, own_ent=own_ent,
+                own_x0=own_x0, own_y0=own_y0, own_wx=own_wx, own_wy=own_wy)
 
 
 class _LossFn(torch.autograd.Function):
@@ -141,11 +157,11 @@ class RadialMRI(Operator):
         key = str(device)
         if key not in self._dev:
             h = self._host
-            t = {k: torch.from_numpy(np.ascontiguousarray(h[k])).to(device)
-                 for k in ("ix0", "iy0", "wx", "wy", "tile_ptr", "tile_ent", "tile_base", "apod")}
+            names = ("ix0", "iy0", "wx", "wy", "tile_ptr", "tile_ent", "tile_base", "apod", "own_ptr", "own_ent",
+                     "own_x0", "own_y0", "own_wx", "own_wy")
+            t = {k: torch.from_numpy(np.ascontiguousarray(h[k])).to(device) for k in names if h[k] is not None}
             plan = _lib.nufft_plan_t(h["R"], h["G"], h["W"], h["J"], h["traj_frames"],
-                                     *[t[k].data_ptr() for k in ("ix0", "iy0", "wx", "wy", "tile_ptr",
-                                                                 "tile_ent", "tile_base", "apod")])
+                                     *[t[k].data_ptr() if k in t else None for k in names])
             self._dev[key] = (plan, t)
         return self._dev[key][0]
 
@@ -222,7 +238,7 @@ class RadialMRI(Operator):
         if y.dim() != 4 or tuple(y.shape[1:]) != (T, self.J, 2) or y.shape[0] not in (1, B):
             raise ValueError("measurement shape %s, expected [1 or %d, %d, %d, 2]" % (tuple(y.shape), B, T, self.J))
         L, plan, st = _lib.lib(), self._plan(dev), _lib.stream_of(x)
-        nblk = L.nufft_interp_blocks(self.J)
+        nblk = L.nufft_interp_parts(C.byref(plan))
         loss = torch.empty(B, device=dev, dtype=torch.float32)
         grad = torch.empty_like(x) if need_grad else None
         t0 = None

@@ -103,3 +103,29 @@ def test_fused_grid_transforms_equal_pad_fft_crop(dev):
     assert_close(out_f, out_l, 2e-6, "adjoint image")
     rc = _lib.lib().nufft_fwd_grid(x.data_ptr(), 36, 5, C.byref(plan), work.data_ptr(), a.data_ptr(), st)
     assert rc != 0 and b"frames" in _lib.lib().step_last_error()
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_tiled_interpolation_equals_the_gathering_kernel(shared, dev):
+    """nufft_interp out of LDS tiles (owner bins in the plan) against the same plan without the
+    bins (every sample gathers from global memory): same products in the same order."""
+    from step_amd.forward_operator import golden_angle_radial
+    traj = golden_angle_radial(1 if shared else 12, 24, 192)
+    rng = np.random.RandomState(3)
+    extra = rng.uniform(-96, 96, (traj.shape[0], 700, 2))
+    extra[:, :4] = [[-96, -96], [96, 96], [-96, 95.99], [0, 0]]          # corners: footprints that wrap
+    traj = np.concatenate([traj, extra], axis=1)
+    a, b = make(spokes=24, frames=12, trajectory=traj), make(spokes=24, frames=12, trajectory=traj)
+    for k in ("own_ptr", "own_ent", "own_x0", "own_y0", "own_wx", "own_wy"):
+        b._host[k] = None
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(5, 12, 2, 192, 192, device=dev, generator=gen)           # 5 chains: a ragged group of 4 + 1
+    ya = a(x)
+    assert_close(ya, b(x), 1e-6, "samples")
+    y = ya[:1] + 0.1 * torch.randn(1, 12, a.J, 2, device=dev, generator=gen)
+    (ga, la), (gb, lb) = a.gradient(x, y, return_loss=True), b.gradient(x, y, return_loss=True)
+    assert_close(la, lb, 1e-6, "loss")
+    assert_close(ga, gb, 1e-6, "gradient")
+    assert_close(a.loss(x, y), b.loss(x, y), 1e-6, "per-chain loss")
+    yb = ya + 0.1 * torch.randn(ya.shape, device=dev, generator=gen)             # a measurement per chain
+    assert_close(a.loss(x, yb), b.loss(x, yb), 1e-6, "per-chain loss, per-chain measurement")
