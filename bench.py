@@ -363,10 +363,11 @@ def main():
             ms = kern["nufft_loss_grad"]
             byts = (16.0 * 12 * 192 * 192 + 8.0 * 12 * op.J) * B     # read x, write grad, read the samples
             gbs = byts / (ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="nufft step (pad, FFT2 384^2, interp, spread, IFFT2, crop)",
+            roof = dict(bound="hbm", kernel="nufft step (row FFT, column FFT, interp, spread, column IFFT, row IFFT)",
                         achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None,
                         algorithmic="(16*T*R*R + 8*T*J) bytes per chain x %d chains; the oversampled grids "
-                                    "(4 x 8*G*G bytes per frame through HBM) are overhead of this design" % B,
+                                    "(per frame 8*G*G bytes written and read once each way, plus the half-height "
+                                    "intermediate of the pruned transforms) are overhead of gridding" % B,
                         kernels_ms=kern)
         elif a.coils > 0:
             ms = kern["mri_loss_grad_mc"]

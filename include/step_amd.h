@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 6 since nufft_plan_t carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 

@@ -17,18 +17,19 @@
 // a >= 12 are image samples, and of the 24 outputs c + 16 d of a pass-B task exactly d < 6 and
 // d >= 18 are image rows.  Column passes: 32 columns per workgroup, tasks laid out column-fastest
 // so that every global access is a 256-byte row segment and the LDS exchange is conflict-free;
-// row passes: 16 rows per workgroup through one LDS tile, loads and stores as whole rows.
+// row passes: 8 rows per workgroup through one LDS tile (five workgroups per CU; 16 rows and two
+// workgroups were 20 % slower), loads and stores as whole rows.
 #include "common.h"
 #include "fft_small.h"
 
 #define NF_R 192
 #define NF_G 384
 #define NF_H 96
-#define NF_CW 32             // columns per workgroup (column passes)
-#define NF_CT 768            // threads: 24 pass-A tasks x 32 columns
-#define NF_RW 16             // rows per workgroup (row passes)
-#define NF_RT 384            // threads: 24 pass-A tasks x 16 rows
-#define NF_RS 400            // LDS row stride of the row passes (slots 25 c + b <= 398)
+#define NF_CW 32             // columns per workgroup (column passes; 16 measured the same)
+#define NF_CT (24 * NF_CW)    // threads: 24 pass-A tasks per column
+#define NF_RW 8              // rows per workgroup (row passes)
+#define NF_RT (24 * NF_RW)    // threads: 24 pass-A tasks per row
+#define NF_RS 408            // LDS row stride of the row passes (slots 25 c + b <= 398; 16 banks between rows)
 
 __device__ __forceinline__ void nf_twiddles(cf32* tw, int tid, int nthreads) {
     for (int m = tid; m < NF_G; m += nthreads) {

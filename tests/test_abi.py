@@ -50,7 +50,7 @@ def test_header_is_plain_c(tmp_path):
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
-    assert _lib.lib().step_abi_version() == 5
+    assert _lib.lib().step_abi_version() == 6
 
 
 def test_host_entry_points_reject_bad_arguments():
