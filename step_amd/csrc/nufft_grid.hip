@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
 #define NI_TILE 32
 #define NI_CH 4
 #define NI_SPAN (NI_TILE + NU_WMAX - 1)
+#define NI_BATCH 20           // grid rows a lane group has in flight while staging (37 or 38 of them per group)
 __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __restrict__ grid, NuPlan p, int T, int B,
                                                             const float2* __restrict__ y, int y_batch,
                                                             float res_scale, float2* __restrict__ out,
@@ -148,76 +149,86 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
         if (loss_part && tid < nc) loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = 0.f;
         return;
     }
+    const int q = tid >> 2, c = tid & 3;                      // this thread's sample slot and chain
+    const size_t tb = (size_t)tf * p.J;
+    const int b = b0 + c;
+    // the tables (and the measurement) of this thread's first sample are requested ahead of the
+    // grid staging and arrive under it; most tiles hold fewer than 64 samples, i.e. one per slot
+    int s = e0 + q, j = 0, lx = 0, ly = 0;
+    bool have = c < nc && s < e1;
+    float wxr[NU_WMAX], wyr[NU_WMAX];
+    float2 m = make_float2(0.f, 0.f);
+    auto fetch = [&]() {
+        j = p.own_ent[tb + s];
+        lx = p.own_x0[tb + s] - tx * NI_TILE;
+        ly = p.own_y0[tb + s] - ty * NI_TILE;
+        const float* wxp = p.own_wx + (tb + s) * W;
+        const float* wyp = p.own_wy + (tb + s) * W;
+#pragma unroll
+        for (int k = 0; k < NU_WMAX; ++k) {
+            wxr[k] = k < W ? wxp[k] : 0.f;
+            wyr[k] = k < W ? wyp[k] : 0.f;
+        }
+        if (y) m = y[((size_t)(y_batch > 1 ? b : 0) * T + t) * p.J + j];
+    };
+    if (have) fetch();
     {
-        // a 64-lane group per grid row (span <= 39 lanes load), four rows per pass, eight passes in
-        // flight: the loads of a pass do not wait for the LDS stores of the one before
+        // a 64-lane group per grid row (span <= 39 lanes load), four rows per pass, NI_BATCH passes
+        // in flight: two rounds of loads per workgroup
         const int lane = tid & 63, rq = tid >> 6, nrows = nc * span;
         const int gx = nu_wrap(tx * NI_TILE + lane, G);
-        for (int r0 = rq; r0 < nrows; r0 += 32) {
-            float2 v[8];
+        for (int r0 = rq; r0 < nrows; r0 += 4 * NI_BATCH) {
+            float2 v[NI_BATCH];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NI_BATCH; ++i) {
                 const int r = r0 + 4 * i;
                 v[i] = make_float2(0.f, 0.f);
                 if (r < nrows && lane < span) {
-                    const int c = r / span, ry = r - c * span;
+                    const int cc = r / span, ry = r - cc * span;
                     const int gy = nu_wrap(ty * NI_TILE + ry, G);
-                    v[i] = grid[((size_t)(b0 + c) * T + t) * G * G + (size_t)gy * G + gx];
+                    v[i] = grid[((size_t)(b0 + cc) * T + t) * G * G + (size_t)gy * G + gx];
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NI_BATCH; ++i) {
                 const int r = r0 + 4 * i;
                 if (r < nrows && lane < span) {
-                    const int c = r / span, ry = r - c * span;
-                    s_g[c][ry * span + lane] = v[i];
+                    const int cc = r / span, ry = r - cc * span;
+                    s_g[cc][ry * span + lane] = v[i];
                 }
             }
         }
     }
     __syncthreads();
-    const int q = tid >> 2, c = tid & 3;                      // this thread's sample slot and chain
-    const size_t tb = (size_t)tf * p.J;
     float acc = 0.f;
-    if (c < nc) {
-        const int b = b0 + c;
-        for (int s = e0 + q; s < e1; s += 64) {
-            const int j = p.own_ent[tb + s];
-            const int lx = p.own_x0[tb + s] - tx * NI_TILE, ly = p.own_y0[tb + s] - ty * NI_TILE;
-            const float* wxp = p.own_wx + (tb + s) * W;
-            const float* wyp = p.own_wy + (tb + s) * W;
-            float wxr[NU_WMAX], wyr[NU_WMAX];
+    while (have) {
+        const float2* g0 = s_g[c] + ly * span + lx;
+        float sr = 0.f, si = 0.f;
 #pragma unroll
-            for (int k = 0; k < NU_WMAX; ++k) {
-                wxr[k] = k < W ? wxp[k] : 0.f;
-                wyr[k] = k < W ? wyp[k] : 0.f;
+        for (int a = 0; a < NU_WMAX; ++a)
+            if (a < W) {
+                const float2* row = g0 + a * span;
+                float rr = 0.f, ri = 0.f;
+#pragma unroll
+                for (int k = 0; k < NU_WMAX; ++k)
+                    if (k < W) {
+                        const float2 v = row[k];
+                        rr += wxr[k] * v.x;
+                        ri += wxr[k] * v.y;
+                    }
+                sr += wyr[a] * rr;
+                si += wyr[a] * ri;
             }
-            const float2* g0 = s_g[c] + ly * span + lx;
-            float sr = 0.f, si = 0.f;
-#pragma unroll
-            for (int a = 0; a < NU_WMAX; ++a)
-                if (a < W) {
-                    const float2* row = g0 + a * span;
-                    float rr = 0.f, ri = 0.f;
-#pragma unroll
-                    for (int k = 0; k < NU_WMAX; ++k)
-                        if (k < W) {
-                            const float2 v = row[k];
-                            rr += wxr[k] * v.x;
-                            ri += wxr[k] * v.y;
-                        }
-                    sr += wyr[a] * rr;
-                    si += wyr[a] * ri;
-                }
-            float2 o = make_float2(sr, si);
-            if (y) {
-                const float2 m = y[((size_t)(y_batch > 1 ? b : 0) * T + t) * p.J + j];
-                const float dr = sr - m.x, di = si - m.y;
-                acc += dr * dr + di * di;
-                o = make_float2(res_scale * dr, res_scale * di);
-            }
-            out[((size_t)b * T + t) * p.J + j] = o;
+        float2 o = make_float2(sr, si);
+        if (y) {
+            const float dr = sr - m.x, di = si - m.y;
+            acc += dr * dr + di * di;
+            o = make_float2(res_scale * dr, res_scale * di);
         }
+        out[((size_t)b * T + t) * p.J + j] = o;
+        s += 64;
+        have = s < e1;
+        if (have) fetch();
     }
     if (loss_part) {
         red[tid] = acc;
