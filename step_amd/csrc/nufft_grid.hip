@@ -11,8 +11,9 @@
 // weights and first grid index are tabulated once per trajectory on the host (fp64 -> fp32), so
 // the kernels do no transcendental work.  Pixel n of an axis has the centred coordinate n - R/2
 // and sits at grid index (n - R/2) mod G; a sample at kappa cycles per field of view sits at grid
-// coordinate 2 kappa.  The FFT between the two halves is a plain library FFT (hipFFT through
-// torch.fft on the same stream) -- the gridding, interpolation and apodisation are these kernels.
+// coordinate 2 kappa.  The grid transforms between the two halves are nufft_fft.hip for R = 192
+// (fused with pad / crop, pruned) and otherwise a library FFT2 (hipFFT through torch.fft on the
+// same stream) between k_nufft_pad_apod and k_nufft_crop_apod.
 //
 // Spreading is a GATHER, not a scatter: the host bins the samples by 16 x 16 grid tile (every tile
 // a sample's W x W footprint touches); one workgroup owns a tile of a frame, stages the tile's
