@@ -484,7 +484,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     constexpr int HH = H / 2, NSTRIP = W / 32, NTILE = HH / 32;
     // optional rider: sum_out = sum(sum_in[0 .. sum_n)) in a fixed order (the scalar loss that
     // gradient(return_loss=True) returns, daps.py:100) -- saves a reduction launch per step
-    if (!FUSED && sum_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    if (!FUSED && sum_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
         float sacc = 0.f;
         for (int i = threadIdx.x; i < sum_n; i += 64) sacc += sum_in[i];
         sacc = wave_sum(sacc);
@@ -528,9 +528,14 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         if (tid < ncp) lcsr[68 + tid] = fz.cp_ent[bcp + tid];           // <= 192 and <= 256 entries:
         if (tid < nca) lcsr[68 + 192 + tid] = fz.ca_ent[bca + tid];     // bh_build_frame_closures
     }
+    // gridDim.y workgroups share a frame's tiles when the chains alone do not fill the chip (one or
+    // two chains per GPU): workgroup blockIdx.y takes the tiles with tile % gridDim.y == blockIdx.y
+    // and stages only their rows of the planes; everything per chain ahead of the tiles is repeated
+    const int tpart = blockIdx.y, tsplit = gridDim.y;
 #pragma unroll
     for (int u = tid; u < 8 * HH; u += S3_THREADS) {
         const int y = u % HH, q = u / HH;                    // q = (part*2 + kb)*2 + h
+        if (tsplit > 1 && (y >> 5) % tsplit != tpart) continue;
         const int hh = q & 1, kb = (q >> 1) & 1, part = q >> 2;
         const float* src = ey_ri + (((size_t)t * 2 + part) * 32 + kb * 16 + hh * 8) * H + y;
         float v[8];
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
             float* gf = (UPD ? up.x : grad) + fo;
             const float* x0f = UPD ? up.x0 + fo : nullptr;
 #pragma unroll 1
-            for (int tile = 0; tile < NTILE; ++tile) {
+            for (int tile = tpart; tile < NTILE; tile += tsplit) {
 
                 f32x16 ev, od;
 #pragma unroll
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
     if (UPD >= 2 && up.nan_flag && __any(bad) && lane == 0 &&
         __hip_atomic_load(up.nan_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         atomicOr(up.nan_flag, 1);
-    if (FUSED && blockIdx.x == 0) {
+    if (FUSED && blockIdx.x == 0 && blockIdx.y == 0) {
         // workgroup 0, once its tiles are stored (off the path of everybody's first store): every
         // chain's loss (and raw chi^2) and their total, in a fixed order:
         // wave w takes chains w, w + 8, ...; the eight partial totals are added in wave order
@@ -808,9 +813,12 @@ static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, 
     s3_grid(B, T, &cpw, &gx);
     const size_t lds = (size_t)24 * (H / 2) * 16 + (size_t)S3_GCH * S3_GROW * 4 + (2 * S3_GCH + 8) * 4 +
                        (68 + 192 + 256) * 4;
+    // fewer workgroups than half the CUs (one or two chains): split a frame's H / 64 tiles over 2 or 4
+    int tsplit = 1;
+    while (2 * tsplit <= (H / 64) && gx * T * tsplit * 2 <= s3_cu_count()) tsplit *= 2;
 #define S3_ADJ_LAUNCH(FU, UP)                                                                              \
     step_allow_lds((const void*)k_dft_adj_s3<H, W, FU, UP>, lds);                                          \
-    hipLaunchKernelGGL((k_dft_adj_s3<H, W, FU, UP>), dim3(gx * T), dim3(S3_THREADS), lds, st, ey_ri, ex_ri, \
+    hipLaunchKernelGGL((k_dft_adj_s3<H, W, FU, UP>), dim3(gx * T, tsplit), dim3(S3_THREADS), lds, st, ey_ri, ex_ri, \
                        gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,    \
                        fz ? *fz : S3FusedAdj{}, up ? *up : S3Update{})
     const int mode = up ? (up->seeds ? 2 + up->p.algo : 1) : 0;     // 2: langevin, 3: hmc (momentum 0)

@@ -525,11 +525,14 @@ class BlackHoleImagingTorch(Operator):
         The struct of the last measurement is kept: a sampler passes the same observation on every
         step, and rebuilding nine tensors per step costs more host time than a small-batch step
         takes on the GPU.  The cache is keyed on the object and on its tensors' storage."""
-        key = (id(y),) + tuple(None if getattr(y, k) is None else
-                               (getattr(y, k).data_ptr(), tuple(getattr(y, k).shape), getattr(y, k)._version)
-                               for k in BlackHoleObservation.FIELDS)
-        if self._meas_cache is not None and self._meas_cache[0] == key:
-            return self._meas_cache[1], self._meas_cache[2]
+        key = [id(y)]
+        for k in BlackHoleObservation.FIELDS:
+            t = getattr(y, k)
+            if t is not None:
+                key += (t.data_ptr(), t._version, t.shape)
+        cache = self._meas_cache
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
         meas, keep = self._meas_build(y)
         self._meas_cache = (key, meas, keep, y)
         return meas, keep
@@ -574,6 +577,8 @@ class BlackHoleImagingTorch(Operator):
     # kernels carry the closure work per chain (+0.2 us per chain and launch pair, rocprofv3,
     # profiles/r02_*): it wins below ~32 chains per GPU, the three-kernel path above.
     fused_max_batch = 31
+    _last_chi2 = None
+    _last_fused = None
 
     def _fused_ok(self, y, B=None):
         if B is not None and B > self.fused_max_batch:
@@ -592,29 +597,57 @@ class BlackHoleImagingTorch(Operator):
         xv = self._video(x)
         B, M, T, dev = xv.shape[0], self.T * self.F, self.T, self.device
         Kcp, Kca = self.cphase_dim, self.logcamp_dim
-        # one allocation for every small buffer: S (16-byte aligned) first
-        sizes = (4 * B * T, 2 * B * M, B * T, B * Kcp, B * Kca, B, 5 * B, 4)
-        buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
-        S, vis, flux, dcp, dca, loss, chi2, total = torch.split(buf, sizes)
+        # one allocation for every small buffer, S (16-byte aligned) first, addressed by offset: at
+        # one chain the step is 26 us on the GPU and every tensor view made here costs about one
+        o_vis = 4 * B * T
+        o_flux = o_vis + 2 * B * M
+        o_dcp = o_flux + B * T
+        o_dca = o_dcp + B * Kcp
+        o_loss = o_dca + B * Kca
+        o_chi2 = o_loss + B
+        o_total = o_chi2 + 5 * B
+        buf = torch.empty(o_total + 4, device=dev, dtype=torch.float32)
+        base = buf.data_ptr()
         grad = None
         if update is None:
             grad = torch.empty(B, T, self.H * self.W, device=dev, dtype=torch.float32)
         elif xv.data_ptr() != x.data_ptr() or update.x_inout != x.data_ptr():
             raise ValueError("in-place update needs a contiguous fp32 state on the operator's device")
-        ws = _lib.bh_step_ws_t(vis.data_ptr(), flux.data_ptr(), dcp.data_ptr(), dca.data_ptr(), S.data_ptr())
+        ws = _lib.bh_step_ws_t(base + 4 * o_vis, base + 4 * o_flux, base + 4 * o_dcp, base + 4 * o_dca, base)
         meas, keep = self._meas(y)
         t0 = self._tick()
         rc = _lib.lib().bh_loss_grad_sep3(
             self._ey_t.data_ptr(), self._ey_ri.data_ptr(), self._ex_ri.data_ptr(), T, self.F, self.H,
             self.W, xv.data_ptr(), B, C.byref(self._tab), self._frame_tab.data_ptr(), C.byref(meas),
-            C.byref(self._weights), C.byref(ws), _lib.ptr(chain_scale), 0.5, loss.data_ptr(),
-            chi2.data_ptr(), total.data_ptr() if want_total else None, _lib.ptr(grad),
+            C.byref(self._weights), C.byref(ws), _lib.ptr(chain_scale), 0.5, base + 4 * o_loss,
+            base + 4 * o_chi2, base + 4 * o_total if want_total else None, _lib.ptr(grad),
             None if update is None else C.byref(update), _lib.stream_of(xv))
         self._tock("fused_step", t0)
         _lib.check(rc, "bh_loss_grad_sep3")
-        self.last_chi2 = chi2.view(B, 5)
-        self.last_vis = torch.view_as_complex(vis.view(B, M, 2))
-        return loss, (total[0] if want_total else None), grad
+        self._last_chi2 = None
+        self._last_fused = (buf, o_vis, o_chi2, B, M)         # last_chi2 / last_vis are made on request
+        return buf[o_loss:o_chi2], (buf[o_total] if want_total else None), grad
+
+    @property
+    def last_chi2(self):
+        """Raw (vis, amp, cphase, logcamp, flux) chi^2 per chain of the last loss evaluation."""
+        if self._last_chi2 is None and self._last_fused is not None:
+            buf, _, o_chi2, B, _ = self._last_fused
+            return buf[o_chi2:o_chi2 + 5 * B].view(B, 5)
+        return self._last_chi2
+
+    @last_chi2.setter
+    def last_chi2(self, value):
+        self._last_chi2 = value
+        self._last_fused = None
+
+    @property
+    def last_vis(self):
+        """Visibilities of the last two-launch step (complex64 [B, T * F])."""
+        if self._last_fused is None:
+            return None
+        buf, o_vis, _, B, M = self._last_fused
+        return torch.view_as_complex(buf[o_vis:o_vis + 2 * B * M].view(B, M, 2))
 
     def _observe(self, vis):
         vis = vis.detach().to(self.device, torch.complex64).contiguous()
