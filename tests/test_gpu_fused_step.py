@@ -91,7 +91,7 @@ def test_fallbacks(dev):
     assert rc == -1 and b"spans frames" in _lib.lib().step_last_error()
 
 
-@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 33)])
+@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 1), (8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 1), (7, 128, 33)])
 def test_descent_step_equals_gradient_then_update(n_sites, imsize, B, dev):
     """descent_step (the update of MCMCSampler.optimize, daps.py:210-223, applied inside the
     adjoint) == gradient() followed by the same arithmetic in torch, on the two-launch path
@@ -140,7 +140,7 @@ def test_optimize_with_and_without_the_fused_descent(dev):
 
 
 @pytest.mark.parametrize("algo", [0, 1])
-@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 33)])
+@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 1), (8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 1), (7, 128, 33)])
 def test_langevin_step_equals_gradient_then_philox_update(n_sites, imsize, B, algo, dev):
     """langevin_step (the step of MCMCSampler.sample for the 'gaussian' prior solver, applied and
     its noise drawn inside the adjoint) == gradient() followed by mcmc_update_philox in the
