@@ -129,3 +129,26 @@ def test_tiled_interpolation_equals_the_gathering_kernel(shared, dev):
     assert_close(a.loss(x, y), b.loss(x, y), 1e-6, "per-chain loss")
     yb = ya + 0.1 * torch.randn(ya.shape, device=dev, generator=gen)             # a measurement per chain
     assert_close(a.loss(x, yb), b.loss(x, yb), 1e-6, "per-chain loss, per-chain measurement")
+
+
+@pytest.mark.parametrize("R", [64, 80])
+def test_other_resolutions_take_the_library_transform(R, dev):
+    """R != 192: pad / crop kernels around the library FFT2 (no own grid transforms); G = 128 has
+    whole 32 x 32 tiles (interpolation out of LDS), G = 160 has too (G % 32 == 0) -- both against
+    the direct NUDFT."""
+    from step_amd.forward_operator import golden_angle_radial
+    frames = 3
+    traj = golden_angle_radial(frames, 9, R)
+    op, orc = make(spokes=9, frames=frames, resolution=R, trajectory=traj), NUDFTOracle(traj, R)
+    assert not op._own_fft()
+    gen = torch.Generator().manual_seed(R)
+    x = torch.randn(2, frames, 2, R, R, generator=gen)
+    y = orc(torch.randn(1, frames, 2, R, R, generator=gen)).float()
+    assert_close(op(x.to(dev)), orc(x), RTOL, "type 2")
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    op.grid_fft = "fused"
+    with pytest.raises(RuntimeError, match="built for R = 192"):
+        op.gradient(x.to(dev), y.to(dev))
