@@ -358,8 +358,8 @@ typedef struct {
     const int64_t* tile_base;  /* [traj_frames] offset of a trajectory frame's list in tile_ent */
     const float* apod;         /* [R] de-apodisation per axis: 1 / (kernel transform at pixel n) */
     /* the six below may all be NULL (then nufft_interp gathers from global memory): every sample once, by the
-     * 32 x 32 grid tile that holds the first point (ix0 mod G, iy0 mod G) of its footprint */
-    const int32_t* own_ptr;    /* [traj_frames][(G/32)^2 + 1] (CSR, per trajectory frame from 0) */
+     * 64 (x) by 32 (y) grid tile that holds the first point (ix0 mod G, iy0 mod G) of its footprint */
+    const int32_t* own_ptr;    /* [traj_frames][(G/64)(G/32) + 1] (CSR, per trajectory frame from 0; tiles row-major) */
     const int32_t* own_ent;    /* [traj_frames][J] sample ids, ascending within a tile */
     const int32_t* own_x0;     /* [traj_frames][J] ix0 mod G, iy0 mod G and the weights once more, */
     const int32_t* own_y0;     /*                  in the order of own_ent (read consecutively) */
@@ -368,7 +368,7 @@ typedef struct {
 } nufft_plan_t;
 
 int nufft_interp_blocks(int J);     /* partial sums per frame of the gathering kernel */
-/* loss_part holds frames * nufft_interp_parts(plan) floats: (G/32)^2 per frame with the owner
+/* loss_part holds frames * nufft_interp_parts(plan) floats: (G/64)(G/32) per frame with the owner
  * bins (the interpolation then runs tile by tile out of LDS), nufft_interp_blocks(J) without. */
 int nufft_interp_parts(const nufft_plan_t* plan);
 int nufft_pad_apod(const float* x, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,

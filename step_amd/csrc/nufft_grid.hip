@@ -35,7 +35,7 @@ struct NuPlan {
     const int32_t* tile_ent;                  // [traj_frames][...] sample ids, ascending per tile
     const int64_t* tile_base;                 // [traj_frames] offset of a trajectory frame's entries in tile_ent
     const float* apod;                        // [R] 1 / kernel transform at pixel n (per axis)
-    const int32_t* own_ptr;                   // [traj_frames][(G/32)^2 + 1] samples by the 32 x 32 tile that holds
+    const int32_t* own_ptr;                   // [traj_frames][(G/64)(G/32) + 1] samples by the 64 x 32 tile that holds
     const int32_t* own_ent;                   // [traj_frames][J]            their footprint's first point, or null;
     const int32_t* own_x0;                    // [traj_frames][J] first point (wrapped into [0, G)) and weights
     const int32_t* own_y0;                    //                  in the order of own_ent
@@ -121,27 +121,30 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
     }
 }
 
-// The same interpolation with the grid staged through LDS: a workgroup owns a 32 x 32 tile of
+// The same interpolation with the grid staged through LDS: a workgroup owns a 64 x 32 tile of
 // frame index t for NI_CH chains, loads the tile plus the W - 1 rows / columns a footprint that
-// starts in it can reach (each grid point crosses HBM about 1.3 times instead of being gathered
+// starts in it can reach (each grid point crosses HBM about 1.25 times instead of being gathered
 // 36 times through L2), then takes the samples whose footprint starts in the tile: the host has
 // binned them (every sample in exactly one tile) and laid their tables out in bin order, so a
 // thread reads its sample's first point and 2 W weights from consecutive memory -- no dependent
 // gathers, no staging, no barrier per batch of samples.  One (sample, chain) pair per thread at a
 // time, the 36 products from LDS in the order of k_nufft_interp.
 // loss_part[f][tile] = the tile's share of sum |yhat - y|^2.
-#define NI_TILE 32
-#define NI_CH 4
-#define NI_SPAN (NI_TILE + NU_WMAX - 1)
-#define NI_BATCH 20           // grid rows a lane group has in flight while staging (37 or 38 of them per group)
+#define NI_TW 64             // tile width: 69-point row segments touch 5 lines of 128 bytes for 552 useful bytes
+#define NI_TH 32
+#define NI_CH 2
+#define NI_SW (NI_TW + NU_WMAX - 1)
+#define NI_SH (NI_TH + NU_WMAX - 1)
+#define NI_BATCH 12          // grid elements a thread has in flight while staging
 __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __restrict__ grid, NuPlan p, int T, int B,
                                                             const float2* __restrict__ y, int y_batch,
                                                             float res_scale, float2* __restrict__ out,
                                                             float* __restrict__ loss_part) {
-    __shared__ float2 s_g[NI_CH][NI_SPAN * NI_SPAN];
+    __shared__ float2 s_g[NI_CH][NI_SH * NI_SW];
     __shared__ float red[256];
-    const int G = p.G, W = p.W, nt = G / NI_TILE, ntiles = nt * nt, span = NI_TILE + W - 1;
-    const int tile = blockIdx.x, ty = tile / nt, tx = tile - ty * nt;
+    const int G = p.G, W = p.W, ntx = G / NI_TW, ntiles = ntx * (G / NI_TH);
+    const int sw = NI_TW + W - 1, sh = NI_TH + W - 1;
+    const int tile = blockIdx.x, ty = tile / ntx, tx = tile - ty * ntx;
     const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * NI_CH, tf = p.traj_frames == 1 ? 0 : t;
     const int nc = min(NI_CH, B - b0), tid = threadIdx.x;
     const int32_t* ptr = p.own_ptr + (size_t)tf * (ntiles + 1);
@@ -150,19 +153,20 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
         if (loss_part && tid < nc) loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = 0.f;
         return;
     }
-    const int q = tid >> 2, c = tid & 3;                      // this thread's sample slot and chain
+    const int q = tid / NI_CH, c = tid - q * NI_CH;           // this thread's sample slot and chain
+    const int nslot = 256 / NI_CH;
     const size_t tb = (size_t)tf * p.J;
     const int b = b0 + c;
     // the tables (and the measurement) of this thread's first sample are requested ahead of the
-    // grid staging and arrive under it; most tiles hold fewer than 64 samples, i.e. one per slot
+    // grid staging and arrive under it; most tiles hold fewer samples than there are slots
     int s = e0 + q, j = 0, lx = 0, ly = 0;
     bool have = c < nc && s < e1;
     float wxr[NU_WMAX], wyr[NU_WMAX];
     float2 m = make_float2(0.f, 0.f);
     auto fetch = [&]() {
         j = p.own_ent[tb + s];
-        lx = p.own_x0[tb + s] - tx * NI_TILE;
-        ly = p.own_y0[tb + s] - ty * NI_TILE;
+        lx = p.own_x0[tb + s] - tx * NI_TW;
+        ly = p.own_y0[tb + s] - ty * NI_TH;
         const float* wxp = p.own_wx + (tb + s) * W;
         const float* wyp = p.own_wy + (tb + s) * W;
 #pragma unroll
@@ -174,28 +178,27 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
     };
     if (have) fetch();
     {
-        // a 64-lane group per grid row (span <= 39 lanes load), four rows per pass, NI_BATCH passes
-        // in flight: two rounds of loads per workgroup
-        const int lane = tid & 63, rq = tid >> 6, nrows = nc * span;
-        const int gx = nu_wrap(tx * NI_TILE + lane, G);
-        for (int r0 = rq; r0 < nrows; r0 += 4 * NI_BATCH) {
+        // consecutive threads take consecutive points of a row segment; NI_BATCH loads per thread
+        // are in flight before the first LDS store
+        const int per = sh * sw, total = nc * per;
+        for (int u0 = tid; u0 < total; u0 += 256 * NI_BATCH) {
             float2 v[NI_BATCH];
 #pragma unroll
             for (int i = 0; i < NI_BATCH; ++i) {
-                const int r = r0 + 4 * i;
+                const int u = u0 + 256 * i;
                 v[i] = make_float2(0.f, 0.f);
-                if (r < nrows && lane < span) {
-                    const int cc = r / span, ry = r - cc * span;
-                    const int gy = nu_wrap(ty * NI_TILE + ry, G);
+                if (u < total) {
+                    const int cc = u / per, r = u - cc * per, ry = r / sw, rx = r - ry * sw;
+                    const int gy = nu_wrap(ty * NI_TH + ry, G), gx = nu_wrap(tx * NI_TW + rx, G);
                     v[i] = grid[((size_t)(b0 + cc) * T + t) * G * G + (size_t)gy * G + gx];
                 }
             }
 #pragma unroll
             for (int i = 0; i < NI_BATCH; ++i) {
-                const int r = r0 + 4 * i;
-                if (r < nrows && lane < span) {
-                    const int cc = r / span, ry = r - cc * span;
-                    s_g[cc][ry * span + lane] = v[i];
+                const int u = u0 + 256 * i;
+                if (u < total) {
+                    const int cc = u / per, r = u - cc * per;
+                    s_g[cc][r] = v[i];
                 }
             }
         }
@@ -203,12 +206,12 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
     __syncthreads();
     float acc = 0.f;
     while (have) {
-        const float2* g0 = s_g[c] + ly * span + lx;
+        const float2* g0 = s_g[c] + ly * sw + lx;
         float sr = 0.f, si = 0.f;
 #pragma unroll
         for (int a = 0; a < NU_WMAX; ++a)
             if (a < W) {
-                const float2* row = g0 + a * span;
+                const float2* row = g0 + a * sw;
                 float rr = 0.f, ri = 0.f;
 #pragma unroll
                 for (int k = 0; k < NU_WMAX; ++k)
@@ -227,17 +230,17 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
             o = make_float2(res_scale * dr, res_scale * di);
         }
         out[((size_t)b * T + t) * p.J + j] = o;
-        s += 64;
+        s += nslot;
         have = s < e1;
         if (have) fetch();
     }
     if (loss_part) {
         red[tid] = acc;
         __syncthreads();
-        if (tid < nc) {                                       // thread c: its chain's 64 partials, in order
-            float s = 0.f;
-            for (int i = 0; i < 64; ++i) s += red[4 * i + tid];
-            loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = s;
+        if (tid < nc) {                                       // thread c: its chain's partials, in slot order
+            float sum = 0.f;
+            for (int i = 0; i < nslot; ++i) sum += red[NI_CH * i + tid];
+            loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = sum;
         }
     }
 }
@@ -382,12 +385,12 @@ extern "C" int nufft_pad_apod(const float* x, int nframes, int T, const nufft_pl
 
 // the tiled kernel needs the owner bins and whole 32 x 32 tiles
 static bool nu_tiled(const nufft_plan_t* p) {
-    return p->own_ptr && p->own_ent && p->own_x0 && p->own_y0 && p->own_wx && p->own_wy && p->G % NI_TILE == 0;
+    return p->own_ptr && p->own_ent && p->own_x0 && p->own_y0 && p->own_wx && p->own_wy && p->G % NI_TW == 0 && p->G % NI_TH == 0;
 }
 
 extern "C" int nufft_interp_parts(const nufft_plan_t* plan) {
     if (!plan) return 0;
-    return nu_tiled(plan) ? (plan->G / NI_TILE) * (plan->G / NI_TILE) : nufft_interp_blocks(plan->J);
+    return nu_tiled(plan) ? (plan->G / NI_TW) * (plan->G / NI_TH) : nufft_interp_blocks(plan->J);
 }
 
 extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,

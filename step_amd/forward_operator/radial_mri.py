@@ -29,7 +29,7 @@ from .base import Operator, register_operator
 __all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
 
 _TILE = 16
-_OWN_TILE = 32                      # tile of the interpolation kernel (NI_TILE in nufft_grid.hip)
+_OWN_TW, _OWN_TH = 64, 32           # tile of the interpolation kernel (NI_TW, NI_TH in nufft_grid.hip)
 
 
 def golden_angle_radial(frames, spokes, resolution):
@@ -77,16 +77,16 @@ def kb_plan(kappa, R, W=6):
         ptrs.append(ptr)
         ents.append(np.array([j for l in lists for j in l], dtype=np.int32))
         base.append(base[-1] + len(ents[-1]))
-    # every sample once, by the 32 x 32 tile in which its footprint starts (the interpolation kernel
+    # every sample once, by the 64 x 32 tile in which its footprint starts (the interpolation kernel
     # stages that tile and the W - 1 points beyond it in LDS); needs whole tiles
     own_ptr = own_ent = own_x0 = own_y0 = own_wx = own_wy = None
-    if G % _OWN_TILE == 0:
-        no = G // _OWN_TILE
-        key = ((i0[..., 1] % G) // _OWN_TILE) * no + (i0[..., 0] % G) // _OWN_TILE        # [Tt, J]
+    if G % _OWN_TW == 0 and G % _OWN_TH == 0:
+        nox, no = G // _OWN_TW, (G // _OWN_TW) * (G // _OWN_TH)
+        key = ((i0[..., 1] % G) // _OWN_TH) * nox + (i0[..., 0] % G) // _OWN_TW          # [Tt, J]
         own_ent = np.argsort(key, axis=1, kind="stable").astype(np.int32)
-        own_ptr = np.zeros((Tt, no * no + 1), np.int32)
+        own_ptr = np.zeros((Tt, no + 1), np.int32)
         for t in range(Tt):
-            own_ptr[t, 1:] = np.cumsum(np.bincount(key[t], minlength=no * no))
+            own_ptr[t, 1:] = np.cumsum(np.bincount(key[t], minlength=no))
         # the tables once more in bin order: the kernel reads a tile's samples from consecutive memory
         take = lambda a: np.take_along_axis(a, own_ent.astype(np.int64).reshape(own_ent.shape + (1,) * (a.ndim - 2)), axis=1)
         own_x0, own_y0 = take((i0[..., 0] % G).astype(np.int32)), take((i0[..., 1] % G).astype(np.int32))
