@@ -353,7 +353,7 @@ typedef struct {
     const int32_t* iy0;
     const float* wx;           /* [traj_frames][J][W] kernel weights along x */
     const float* wy;
-    const int32_t* tile_ptr;   /* [traj_frames][(G/16)^2 + 1] samples touching each 16 x 16 grid tile (CSR) */
+    const int32_t* tile_ptr;   /* [traj_frames][(G/16)(G/4) + 1] samples touching each 16 (x) by 4 (y) grid tile (CSR, tiles row-major) */
     const int32_t* tile_ent;   /* sample ids, ascending within a tile */
     const int64_t* tile_base;  /* [traj_frames] offset of a trajectory frame's list in tile_ent */
     const float* apod;         /* [R] de-apodisation per axis: 1 / (kernel transform at pixel n) */

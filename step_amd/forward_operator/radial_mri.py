@@ -28,7 +28,7 @@ from .base import Operator, register_operator
 
 __all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
 
-_TILE = 16
+_TW, _TH = 16, 4                    # tile of a wave of the spread kernel (nufft_grid.hip)
 _OWN_TW, _OWN_TH = 64, 32           # tile of the interpolation kernel (NI_TW, NI_TH in nufft_grid.hip)
 
 
@@ -50,7 +50,7 @@ def _kb(d, W, beta):
 def kb_plan(kappa, R, W=6):
     """Host tables of the gridding plan for a trajectory ``kappa`` [Tt, J, 2] (fp64 arithmetic):
     first grid index and W separable Kaiser-Bessel weights per sample and axis on the G = 2 R
-    grid (beta from Beatty et al. 2005 for oversampling 2), the samples binned by 16 x 16 grid tile,
+    grid (beta from Beatty et al. 2005 for oversampling 2), the samples binned by 16 x 4 grid tile,
     and the de-apodisation 1 / phi_hat at the pixel positions."""
     kappa = np.asarray(kappa, dtype=np.float64)
     Tt, J, _ = kappa.shape
@@ -62,17 +62,19 @@ def kb_plan(kappa, R, W=6):
     i0 = np.ceil(u - W / 2.0).astype(np.int64)                      # [Tt, J, 2]
     off = i0[..., None] + np.arange(W) - u[..., None]               # [Tt, J, 2, W] in [-W/2, W/2)
     w = _kb(off, W, beta)
-    nt = G // _TILE
+    if G % _TW:
+        raise ValueError("the oversampled grid G = %d must be a multiple of %d" % (G, _TW))
+    ntx, nty = G // _TW, G // _TH
     ptrs, ents, base = [], [], [0]
     for t in range(Tt):
-        lists = [[] for _ in range(nt * nt)]
+        lists = [[] for _ in range(ntx * nty)]
         for j in range(J):
-            xs = sorted({((i0[t, j, 0] + k) % G) // _TILE for k in range(W)})
-            ys = sorted({((i0[t, j, 1] + k) % G) // _TILE for k in range(W)})
+            xs = sorted({((i0[t, j, 0] + k) % G) // _TW for k in range(W)})
+            ys = sorted({((i0[t, j, 1] + k) % G) // _TH for k in range(W)})
             for ty in ys:
                 for tx in xs:
-                    lists[ty * nt + tx].append(j)
-        ptr = np.zeros(nt * nt + 1, np.int32)
+                    lists[ty * ntx + tx].append(j)
+        ptr = np.zeros(ntx * nty + 1, np.int32)
         ptr[1:] = np.cumsum([len(l) for l in lists])
         ptrs.append(ptr)
         ents.append(np.array([j for l in lists for j in l], dtype=np.int32))
