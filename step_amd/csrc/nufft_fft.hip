@@ -135,18 +135,29 @@ __global__ __launch_bounds__(NF_RT) void k_nufft_rows_fwd(const float* __restric
     const float* xr = x + (size_t)f * 2 * NF_R * NF_R;
     const float* xi = xr + (size_t)NF_R * NF_R;
     nf_twiddles(tw, tid, NF_RT);
-    for (int i = tid; i < NF_RW * NF_R; i += NF_RT) {
-        const int row = i / NF_R, n = i - row * NF_R, y = y0 + row;
-        const float a = apod[y] * apod[n];
-        const int g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
-        buf[row * NF_RS + g] = c_make(a * xr[y * NF_R + n], a * xi[y * NF_R + n]);
+    static_assert(NF_RT == NF_R, "one thread per pixel column");
+    {
+        const int n = tid, g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
+        const float an = apod[n];
+        float vr[NF_RW], vi[NF_RW];
+#pragma unroll
+        for (int row = 0; row < NF_RW; ++row) {
+            vr[row] = xr[(y0 + row) * NF_R + n];
+            vi[row] = xi[(y0 + row) * NF_R + n];
+        }
+#pragma unroll
+        for (int row = 0; row < NF_RW; ++row) {
+            const float a = apod[y0 + row] * an;
+            buf[row * NF_RS + g] = c_make(a * vr[row], a * vi[row]);
+        }
     }
     __syncthreads();
     nf_rows_in_lds<-1, true>(buf, tw, tid);
     cf32* dst = T + ((size_t)f * NF_R + y0) * NF_G;
-    for (int i = tid; i < NF_RW * NF_G; i += NF_RT) {
-        const int row = i / NF_G, k = i - row * NF_G;
-        dst[(size_t)row * NF_G + k] = buf[row * NF_RS + k];
+#pragma unroll
+    for (int row = 0; row < NF_RW; ++row) {
+        dst[(size_t)row * NF_G + tid] = buf[row * NF_RS + tid];
+        dst[(size_t)row * NF_G + NF_R + tid] = buf[row * NF_RS + NF_R + tid];
     }
 }
 
@@ -161,21 +172,33 @@ __global__ __launch_bounds__(NF_RT) void k_nufft_rows_inv(const cf32* __restrict
     const float cs = out_scale * (chain_scale ? chain_scale[f / frames_per_chain] : 1.f);
     nf_twiddles(tw, tid, NF_RT);
     const cf32* src = T + ((size_t)f * NF_R + y0) * NF_G;
-    for (int i = tid; i < NF_RW * NF_G; i += NF_RT) {
-        const int row = i / NF_G, k = i - row * NF_G;
-        buf[row * NF_RS + k] = src[(size_t)row * NF_G + k];
+    {
+        cf32 v[2 * NF_RW];                                    // all of the tile in flight at once
+#pragma unroll
+        for (int row = 0; row < NF_RW; ++row) {
+            v[2 * row] = src[(size_t)row * NF_G + tid];
+            v[2 * row + 1] = src[(size_t)row * NF_G + NF_R + tid];
+        }
+#pragma unroll
+        for (int row = 0; row < NF_RW; ++row) {
+            buf[row * NF_RS + tid] = v[2 * row];
+            buf[row * NF_RS + NF_R + tid] = v[2 * row + 1];
+        }
     }
     __syncthreads();
     nf_rows_in_lds<1, false>(buf, tw, tid);
     float* outr = out + (size_t)f * 2 * NF_R * NF_R;
     float* outi = outr + (size_t)NF_R * NF_R;
-    for (int i = tid; i < NF_RW * NF_R; i += NF_RT) {
-        const int row = i / NF_R, n = i - row * NF_R, y = y0 + row;
-        const float a = cs * apod[y] * apod[n];
-        const int g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
-        const cf32 v = buf[row * NF_RS + g];
-        outr[y * NF_R + n] = a * v.x;
-        outi[y * NF_R + n] = a * v.y;
+    {
+        const int n = tid, g = n < NF_H ? n + (NF_G - NF_H) : n - NF_H;
+        const float an = cs * apod[n];
+#pragma unroll
+        for (int row = 0; row < NF_RW; ++row) {
+            const float a = an * apod[y0 + row];
+            const cf32 v = buf[row * NF_RS + g];
+            outr[(y0 + row) * NF_R + n] = a * v.x;
+            outi[(y0 + row) * NF_R + n] = a * v.y;
+        }
     }
 }
 
