@@ -24,6 +24,10 @@ def run(args):
 
 
 @pytest.mark.parametrize("args,chains", [(["--batch", "4"], 4),
+                                         (["--batch", "33"], 33),
+                                         (["--path", "sep", "--batch", "2"], 2),
+                                         (["--path", "dense", "--batch", "2"], 2),
+                                         (["--task", "mri", "--coils", "1", "--batch", "2"], 2),
                                          (["--task", "mri", "--batch", "8"], 8),
                                          (["--task", "mri", "--coils", "3", "--batch", "2"], 2),
                                          (["--task", "mri_radial", "--batch", "2"], 2)])
