@@ -67,3 +67,15 @@ sampler:
     assert op.acc_factor == 8 and op.mode == "split_mask"
     stats = run_task.main(["--task", "mri", "--config", str(p), "--num-samples", "2"])
     assert stats[0]["finite"]
+
+
+@pytest.mark.parametrize("extra", [["--pixel-space"], ["--noise", "torch"], ["--prior-solver", "gaussian", "--max-batch", "2"]])
+@pytest.mark.parametrize("task", ["blackhole", "mri"])
+def test_run_task_variants(task, extra, dev):
+    """The runner's other routes end to end: optimize() on decoded frames (the operators' in-kernel
+    descent where there is one), torch noise, the 'gaussian' prior solver with chunked chains."""
+    from step_amd import run_task
+    stats = run_task.main(["--task", task, "--num-samples", "3", "--annealing-steps", "2", "--mcmc-steps", "3",
+                           "--diffusion-steps", "2"] + extra)
+    assert len(stats) == 1 and stats[0]["finite"] and stats[0]["samples"] == 3
+    assert stats[0]["metric_min"] == stats[0]["metric_min"]                 # not NaN
