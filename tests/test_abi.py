@@ -47,6 +47,32 @@ def test_header_is_plain_c(tmp_path):
         assert ctypes.sizeof(getattr(_lib, n)) == sz, n
 
 
+def test_plain_c_program_links_and_runs(tmp_path):
+    """A C99 program (no Python, no torch) links against libstep_amd.so and calls its host entry
+    points: the ABI version, a support query, and the MRI row mask of the shipped configuration
+    (52 of 192 rows at acc_factor 6 with 24 ACS lines, dynamic_mri.py:9-39)."""
+    import subprocess
+    from step_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    src = tmp_path / "use.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "step_amd.h"
+int main(void) {
+    float m[192];
+    int rc = mri_build_mask(6, 0, 192, 1, 24, m), kept = 0, i;
+    for (i = 0; i < 192; ++i) kept += m[i] != 0.f;
+    printf("%d %d %d %d %d\n", step_abi_version(), rc, kept, bh_sep3_supported(256, 256), bh_sep3_supported(100, 100));
+    return 0;
+}
+""")
+    exe = tmp_path / "use"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lstep_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == [_lib.lib().step_abi_version(), 0, 52, 1, 0]
+
+
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
