@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 6 since nufft_plan_t carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -365,6 +365,15 @@ typedef struct {
     const int32_t* own_y0;     /*                  in the order of own_ent (read consecutively) */
     const float* own_wx;       /* [traj_frames][J][W] */
     const float* own_wy;
+    /* the three below may all be NULL (then nufft_spread always runs the kernel that takes 8 chains per tile):
+     * the samples touching each 16 (x) by 2 (y) grid tile with their weights AT THE TILE'S POINTS, for the
+     * spread kernel that gives every chain a lane (used from 16 chains on; bit-identical for finite input) */
+    const int32_t* wide_rec;   /* [traj_frames][(G/16)(G/2)][16]: tile (row-major id), its first entry in wide_ent /
+                                  wide_w, its entries (a multiple of 4: padded with zero-weight entries), 0, the
+                                  sample ids of its first 8 entries (any valid id where the list is shorter), 0 x 4
+                                  -- in the order the kernel should take the tiles (longest lists first) */
+    const int32_t* wide_ent;   /* sample ids, ascending within a tile (padding: any valid id) */
+    const float* wide_w;       /* [entries][2][16] fp32 product wy[gy - iy0] * wx[gx - ix0] on the torus, 0 outside the footprint */
 } nufft_plan_t;
 
 int nufft_interp_blocks(int J);     /* partial sums per frame of the gathering kernel */

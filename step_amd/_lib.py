@@ -46,7 +46,8 @@ class nufft_plan_t(C.Structure):
     _fields_ = [("R", C.c_int32), ("G", C.c_int32), ("W", C.c_int32), ("J", C.c_int32), ("traj_frames", C.c_int32),
                 ("ix0", c_p), ("iy0", c_p), ("wx", c_p), ("wy", c_p), ("tile_ptr", c_p), ("tile_ent", c_p),
                 ("tile_base", c_p), ("apod", c_p), ("own_ptr", c_p), ("own_ent", c_p),
-                ("own_x0", c_p), ("own_y0", c_p), ("own_wx", c_p), ("own_wy", c_p)]
+                ("own_x0", c_p), ("own_y0", c_p), ("own_wx", c_p), ("own_wy", c_p),
+                ("wide_rec", c_p), ("wide_ent", c_p), ("wide_w", c_p)]
 
 
 class mcmc_params_t(C.Structure):

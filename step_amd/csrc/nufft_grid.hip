@@ -41,6 +41,10 @@ struct NuPlan {
     const int32_t* own_y0;                    //                  in the order of own_ent
     const float* own_wx;                      // [traj_frames][J][W]
     const float* own_wy;
+    int wide_tiles;                           // (G / 16) x (G / 2) tiles of 16 x 2 points (k_nufft_spread_wide), or 0
+    const int32_t* wide_rec;                  // [traj_frames][wide_tiles][16] (tile, first entry, entries, 0, first 8 ids, 0 x 4) in launch order
+    const int32_t* wide_ent;                  // sample ids, ascending per tile, lists padded to multiples of 4
+    const float* wide_w;                      // [entries][2][16] weight of the entry's sample at each point of its tile
 };
 
 __device__ __forceinline__ int nu_wrap(int i, int G) { return i < 0 ? i + G : (i >= G ? i - G : i); }
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
 #define NI_CH 2
 #define NI_SW (NI_TW + NU_WMAX - 1)
 #define NI_SH (NI_TH + NU_WMAX - 1)
-#define NI_BATCH 12          // grid elements a thread has in flight while staging
+#define NI_BATCH 10          // rows a wave has in flight while staging
 __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __restrict__ grid, NuPlan p, int T, int B,
                                                             const float2* __restrict__ y, int y_batch,
                                                             float res_scale, float2* __restrict__ out,
@@ -178,30 +182,55 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
     };
     if (have) fetch();
     {
-        // consecutive threads take consecutive points of a row segment; NI_BATCH loads per thread
-        // are in flight before the first LDS store
-        const int per = sh * sw, total = nc * per;
-        for (int u0 = tid; u0 < total; u0 += 256 * NI_BATCH) {
+        // A wave takes whole rows of the staged region (rows w, w + 4, ... of nc * sh): its lanes load the
+        // first 64 points of the row, NI_BATCH rows in flight before the first LDS store; the sw - 64 points
+        // beyond are taken eight to a row afterwards.  No division anywhere: the flat index this loop used to
+        // split into (chain, row, column) by run-time divisors cost 1800 vector instructions per wave and
+        // made the kernel ALU-bound (77 % of the cycles) while it moved 2.7 TB/s.
+        const int wv = tid >> 6, lane = tid & 63, rows = nc * sh;
+        const int gx0 = nu_wrap(tx * NI_TW + lane, G);
+        const float2* gb = grid + ((size_t)b0 * T + t) * G * G;
+        const size_t cstride = (size_t)T * G * G;
+        for (int r0 = wv; r0 < rows; r0 += 4 * NI_BATCH) {
             float2 v[NI_BATCH];
 #pragma unroll
             for (int i = 0; i < NI_BATCH; ++i) {
-                const int u = u0 + 256 * i;
-                v[i] = make_float2(0.f, 0.f);
-                if (u < total) {
-                    const int cc = u / per, r = u - cc * per, ry = r / sw, rx = r - ry * sw;
-                    const int gy = nu_wrap(ty * NI_TH + ry, G), gx = nu_wrap(tx * NI_TW + rx, G);
-                    v[i] = grid[((size_t)(b0 + cc) * T + t) * G * G + (size_t)gy * G + gx];
+                const int r = r0 + 4 * i;
+                if (r < rows) {
+                    const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;             // NI_CH == 2
+                    v[i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx0];
                 }
             }
 #pragma unroll
             for (int i = 0; i < NI_BATCH; ++i) {
-                const int u = u0 + 256 * i;
-                if (u < total) {
-                    const int cc = u / per, r = u - cc * per;
-                    s_g[cc][r] = v[i];
+                const int r = r0 + 4 * i;
+                if (r < rows) {
+                    const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
+                    s_g[cc][ry * sw + lane] = v[i];
                 }
             }
         }
+        static_assert(NI_CH == 2 && NU_WMAX - 1 <= 8, "row split of the staging loop");
+        const int rx = 64 + (tid & 7);
+        const int gx1 = nu_wrap(tx * NI_TW + rx, G);
+        float2 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            if (r < rows && rx < sw) {
+                const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
+                v[i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx1];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            if (r < rows && rx < sw) {
+                const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
+                s_g[cc][ry * sw + rx] = v[i];
+            }
+        }
+        static_assert(3 * 32 >= NI_CH * NI_SH, "the remainder pass covers every row");
     }
     __syncthreads();
     float acc = 0.f;
@@ -321,6 +350,94 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
         if (c < nc) grid[(((size_t)(b0 + c) * T + t) * G + gy) * G + gx] = make_float2(ar[c], ai[c]);
 }
 
+// The same sums with A LANE PER CHAIN, for batches that fill a wave.  k_nufft_spread spends its time
+// finding out which of a tile's 64 points a sample reaches and broadcasting the sample's values to
+// them through LDS (8 ds_read_b64 per list entry and 8 chains: the LDS pipe, shared by the CU's four
+// SIMDs, is what pins it at 0.38 ms whatever the instruction count).  Here a single-wave workgroup
+// owns a 16 x 2 tile of frame index t for 64 chains: lane c holds chain c's 32 sums, an entry's 32
+// weights (host table: w_y w_x at each point of the tile, zero outside the footprint) are the same for
+// every lane and arrive in SCALAR registers, an entry costs one 8-byte load per lane and 64 v_fmac
+// with a scalar operand -- no test, no LDS, no divergence; each entry serves 64 chains, so the list
+// walk is paid once per 64 instead of once per 8.  The sums are transposed through LDS (one row of
+// 16 points at a time, stride 17: conflict-free both ways) so that the grid is still written as
+// 128-byte row segments.  Terms are added in list order (ascending j) with the same rounding
+// (fp32 product of the two weights, then fma): bit-identical to k_nufft_spread for finite input; a
+// zero weight times a non-finite value would reach points the footprint does not (the other kernel
+// skips them).
+// A tile's record (id, first entry, entries) is one 16-byte scalar load; the tiles are launched longest
+// list first (the four tiles around k = 0 hold ~200 entries against a median of 6).
+#define NW_TW 16
+#define NW_TH 2
+#define NW_PTS (NW_TW * NW_TH)
+#define NW_PAD 4             // the host pads every list to a multiple of this
+#define NW_CHUNK 4           // entries whose values are requested together (= NW_PAD)
+#define NW_RP 16             // points per transposition round: 128-byte row segments (64-byte ones: 285 -> 389 us)
+#define NW_REC 16            // ints per tile record
+#define NW_LS (NW_RP + 1)
+#define NW_MIN_CHAINS 16
+__global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restrict__ vals, NuPlan p, int T, int B,
+                                                          float2* __restrict__ grid) {
+    __shared__ float2 s_tr[64 * NW_LS];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * 64, tf = p.traj_frames == 1 ? 0 : t;
+    const int nc = min(64, B - b0);
+    const int G = p.G, ntx = G / NW_TW;
+    // the tile's record: id, first entry, entries, 0, then the sample ids of its first eight entries -- their
+    // values are requested after ONE trip to memory (record -> ids -> values would be two; under the
+    // kernel's own write stream every dependent trip costs microseconds)
+    const int32_t* __restrict__ rp = p.wide_rec + ((size_t)tf * p.wide_tiles + blockIdx.x) * NW_REC;
+    const int4 rec = *(const int4*)rp;
+    const int4 ja = *(const int4*)(rp + 4), jb = *(const int4*)(rp + 8);
+    const int32_t* __restrict__ ent = p.wide_ent;
+    const float* __restrict__ wts = p.wide_w;
+    const float2* __restrict__ v = vals + ((size_t)(b0 + min(lane, nc - 1)) * T + t) * p.J;
+    float ar[NW_PTS], ai[NW_PTS];
+#pragma unroll
+    for (int k = 0; k < NW_PTS; ++k) ar[k] = ai[k] = 0.f;
+    auto add = [&](int e, const float2 (&x)[NW_CHUNK]) {
+#pragma unroll
+        for (int u = 0; u < NW_CHUNK; ++u) {
+            const float* __restrict__ w = wts + (size_t)(e + u) * NW_PTS;
+#pragma unroll
+            for (int k = 0; k < NW_PTS; ++k) {
+                ar[k] = fmaf(w[k], x[u].x, ar[k]);
+                ai[k] = fmaf(w[k], x[u].y, ai[k]);
+            }
+        }
+    };
+    {
+        const float2 xa[NW_CHUNK] = {v[ja.x], v[ja.y], v[ja.z], v[ja.w]};     // valid ids even where the list is shorter
+        const float2 xb[NW_CHUNK] = {v[jb.x], v[jb.y], v[jb.z], v[jb.w]};
+        if (rec.z > 0) add(rec.y, xa);
+        if (rec.z > NW_CHUNK) add(rec.y + NW_CHUNK, xb);
+    }
+    for (int e = rec.y + 2 * NW_CHUNK; e < rec.y + rec.z; e += NW_CHUNK) {
+        float2 x[NW_CHUNK];
+#pragma unroll
+        for (int u = 0; u < NW_CHUNK; ++u) x[u] = v[ent[e + u]];
+        add(e, x);
+    }
+    const int ty = rec.x / ntx, tx = rec.x - ty * ntx;
+    const int cl = lane / NW_RP, px = lane % NW_RP;           // store role: 64 / NW_RP chains x one row segment
+#pragma unroll
+    for (int r = 0; r < NW_PTS / NW_RP; ++r) {
+#pragma unroll
+        for (int k = 0; k < NW_RP; ++k) s_tr[lane * NW_LS + k] = make_float2(ar[r * NW_RP + k], ai[r * NW_RP + k]);
+        __syncthreads();
+        float2* dst = grid + (((size_t)b0 * T + t) * G + ty * NW_TH + (r * NW_RP) / NW_TW) * G + tx * NW_TW + (r * NW_RP) % NW_TW + px;
+#pragma unroll
+        for (int i = 0; i < NW_RP; ++i) {
+            const int c = (64 / NW_RP) * i + cl;
+            if (c < nc) {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const float2 o = s_tr[c * NW_LS + px];
+                __builtin_nontemporal_store(f2v{o.x, o.y}, (f2v*)(dst + (size_t)c * T * G * G));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // out[f][0/1][y][x] = scale * apod[y] apod[x] * Re/Im grid[f][(y - R/2) mod G][(x - R/2) mod G]
 __global__ __launch_bounds__(256) void k_nufft_crop_apod(const float2* __restrict__ grid, NuPlan p, int T,
                                                          const float* __restrict__ chain_scale,
@@ -381,7 +498,9 @@ static int nu_check(const char* who, const nufft_plan_t* p, int nframes, int T) 
 static NuPlan nu_plan(const nufft_plan_t* p) {
     return NuPlan{p->R, p->G, p->W, p->J, p->traj_frames, (p->G / NU_TILE) * (p->G / 4), p->ix0, p->iy0, p->wx, p->wy,
                   p->tile_ptr, p->tile_ent, p->tile_base, p->apod, p->own_ptr, p->own_ent, p->own_x0, p->own_y0,
-                  p->own_wx, p->own_wy};
+                  p->own_wx, p->own_wy,
+                  (p->wide_rec && p->wide_ent && p->wide_w) ? (p->G / NW_TW) * (p->G / NW_TH) : 0,
+                  p->wide_rec, p->wide_ent, p->wide_w};
 }
 
 extern "C" int nufft_interp_blocks(int J) { return (J + 255) / 256; }
@@ -442,6 +561,14 @@ extern "C" int nufft_spread(const float* vals_c64, int nframes, int T, const nuf
     if (int rc = nu_check("nufft_spread", plan, nframes, T)) return rc;
     const NuPlan p = nu_plan(plan);
     const int B = nframes / T;
+    if (p.wide_tiles && B >= NW_MIN_CHAINS) {                   // a lane per chain
+        const int ny = T * ((B + 63) / 64);
+        STEP_REQUIRE(p.G % NW_TW == 0 && ny <= 65535, "nufft_spread: G = %d, %d chains x %d frames", p.G, B, T);
+        hipLaunchKernelGGL(k_nufft_spread_wide, dim3(p.wide_tiles, ny), dim3(64), 0, (hipStream_t)stream,
+                           (const float2*)vals_c64, p, T, B, (float2*)grid_c64);
+        STEP_CHECK_LAUNCH("nufft_spread (wide)");
+        return STEP_OK;
+    }
     hipLaunchKernelGGL(k_nufft_spread, dim3((p.G / NU_TILE) * (p.G / NU_TILE), T * ((B + NU_CH - 1) / NU_CH)),
                        dim3(256), 0, (hipStream_t)stream, (const float2*)vals_c64, p, T, B,
                        (float2*)grid_c64);

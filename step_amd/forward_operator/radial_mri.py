@@ -30,6 +30,7 @@ __all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
 
 _TW, _TH = 16, 4                    # tile of a wave of the spread kernel (nufft_grid.hip)
 _OWN_TW, _OWN_TH = 64, 32           # tile of the interpolation kernel (NI_TW, NI_TH in nufft_grid.hip)
+_WIDE_TW, _WIDE_TH, _WIDE_PAD = 16, 2, 4     # tile and list padding of the lane-per-chain spread kernel (NW_*)
 
 
 def golden_angle_radial(frames, spokes, resolution):
@@ -45,6 +46,48 @@ def golden_angle_radial(frames, spokes, resolution):
 def _kb(d, W, beta):
     a = 1.0 - (2.0 * d / W) ** 2
     return np.where(a >= 0, np.i0(beta * np.sqrt(np.maximum(a, 0.0))), 0.0) / np.i0(beta)
+
+
+def _wide_lists(i0, w32, G, W):
+    """Lists of the spread kernel that gives every chain a lane (k_nufft_spread_wide): per
+    trajectory frame the samples touching each 16 x 2 grid tile, ascending, every list padded to a
+    multiple of 4 with zero-weight entries; per entry the fp32 product wy * wx at each of the tile's
+    32 points (zero outside the sample's footprint); per trajectory frame the records (tile, first
+    entry, entries, 0, ids of the first 8 entries, 0 x 4) by falling list length -- the order in which the kernel's waves take them."""
+    Tt, J = i0.shape[:2]
+    ntx, ntiles = G // _WIDE_TW, (G // _WIDE_TW) * (G // _WIDE_TH)
+    k = np.arange(W)
+    recs, ents, wts, base = [], [], [], 0
+    for t in range(Tt):
+        x0, y0 = i0[t, :, 0] % G, i0[t, :, 1] % G
+        tx = ((x0[:, None] + k) % G) // _WIDE_TW                   # [J, W] tile column of every footprint column
+        ty = ((y0[:, None] + k) % G) // _WIDE_TH
+        key = (ty[:, :, None] * ntx + tx[:, None, :]).astype(np.int64) * J + np.arange(J)[:, None, None]
+        key = np.unique(key.ravel())                                # by tile, then by sample id
+        tile, j = key // J, key % J
+        cnt = np.bincount(tile, minlength=ntiles)
+        padded = cnt + (-cnt) % _WIDE_PAD
+        ptr = np.zeros(ntiles + 1, np.int64)
+        ptr[1:] = np.cumsum(padded)
+        pos = ptr[tile] + np.arange(len(key)) - (np.cumsum(cnt) - cnt)[tile]
+        ent = np.zeros(ptr[-1], np.int32)
+        wt = np.zeros((ptr[-1], _WIDE_TH, _WIDE_TW), np.float32)
+        ent[pos] = j
+        dy = ((tile // ntx)[:, None] * _WIDE_TH + np.arange(_WIDE_TH) - y0[j][:, None]) % G      # [E, 2]
+        dx = ((tile % ntx)[:, None] * _WIDE_TW + np.arange(_WIDE_TW) - x0[j][:, None]) % G       # [E, 16]
+        wy = np.where(dy < W, np.take_along_axis(w32[t, j, 1], np.minimum(dy, W - 1), axis=1), np.float32(0))
+        wx = np.where(dx < W, np.take_along_axis(w32[t, j, 0], np.minimum(dx, W - 1), axis=1), np.float32(0))
+        wt[pos] = wy[:, :, None] * wx[:, None, :]                   # fp32 x fp32 -> fp32, as the other kernel rounds it
+        order = np.argsort(-cnt, kind="stable")
+        rec = np.zeros((ntiles, 16), np.int32)
+        rec[:, 0], rec[:, 1], rec[:, 2] = order, base + ptr[:-1][order], padded[order]
+        first = ptr[:-1][order][:, None] + np.arange(8)                     # a list's first 8 entries (0 beyond its end)
+        rec[:, 4:12] = np.where(np.arange(8) < padded[order][:, None], ent[np.minimum(first, len(ent) - 1)], 0)
+        recs.append(rec)
+        ents.append(ent)
+        wts.append(wt)
+        base += len(ent)
+    return dict(wide_rec=np.stack(recs), wide_ent=np.concatenate(ents), wide_w=np.concatenate(wts))
 
 
 def kb_plan(kappa, R, W=6):
@@ -97,7 +140,9 @@ def kb_plan(kappa, R, W=6):
     d = np.linspace(-W / 2.0, W / 2.0, 4001)
     nu = (np.arange(R) - R / 2) / G
     phat = np.trapezoid(_kb(d, W, beta)[None, :] * np.cos(2 * math.pi * nu[:, None] * d[None, :]), d, axis=1)
-    return dict(R=R, G=G, W=W, J=J, traj_frames=Tt,
+    wide = _wide_lists(i0, w.astype(np.float32), G, W) if G % _WIDE_TW == 0 else \
+        dict(wide_rec=None, wide_ent=None, wide_w=None)
+    return dict(**wide, R=R, G=G, W=W, J=J, traj_frames=Tt,
                 ix0=i0[..., 0].astype(np.int32), iy0=i0[..., 1].astype(np.int32),
                 wx=w[:, :, 0].astype(np.float32), wy=w[:, :, 1].astype(np.float32),
                 tile_ptr=np.stack(ptrs), tile_ent=np.concatenate(ents), tile_base=np.array(base[:-1], np.int64),
@@ -162,7 +207,7 @@ class RadialMRI(Operator):
         if key not in self._dev:
             h = self._host
             names = ("ix0", "iy0", "wx", "wy", "tile_ptr", "tile_ent", "tile_base", "apod", "own_ptr", "own_ent",
-                     "own_x0", "own_y0", "own_wx", "own_wy")
+                     "own_x0", "own_y0", "own_wx", "own_wy", "wide_rec", "wide_ent", "wide_w")
             t = {k: torch.from_numpy(np.ascontiguousarray(h[k])).to(device) for k in names if h[k] is not None}
             plan = _lib.nufft_plan_t(h["R"], h["G"], h["W"], h["J"], h["traj_frames"],
                                      *[t[k].data_ptr() if k in t else None for k in names])

@@ -152,3 +152,41 @@ def test_other_resolutions_take_the_library_transform(R, dev):
     op.grid_fft = "fused"
     with pytest.raises(RuntimeError, match="built for R = 192"):
         op.gradient(x.to(dev), y.to(dev))
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_lane_per_chain_spread_equals_the_tile_kernel(shared, dev):
+    """nufft_spread from 16 chains on (a lane per chain, 16 x 2 tiles, weights from the plan's table)
+    against the same plan without those lists (8 chains per 16 x 4 tile): the same terms in the same
+    order, bit for bit; ragged chain counts, footprints that wrap, more than one group of 64; and
+    against the direct NUDFT's adjoint."""
+    import ctypes as C
+    from step_amd import _lib
+    from step_amd.forward_operator import golden_angle_radial
+    frames = 3 if shared else 12
+    traj = golden_angle_radial(1 if shared else frames, 24, 192)
+    rng = np.random.RandomState(4)
+    extra = rng.uniform(-96, 96, (traj.shape[0], 300, 2))
+    extra[:, :4] = [[-96, -96], [96, 96], [-96, 95.99], [0, 0]]
+    traj = np.concatenate([traj, extra], axis=1)
+    a, b = make(spokes=24, frames=frames, trajectory=traj), make(spokes=24, frames=frames, trajectory=traj)
+    assert a._host["wide_rec"] is not None and (a._host["wide_rec"][:, :, 2] % 4 == 0).all()
+    for k in ("wide_rec", "wide_ent", "wide_w"):
+        b._host[k] = None
+    gen = torch.Generator(device=dev).manual_seed(11)
+    L = _lib.lib()
+    for B in (16, 37, 70):
+        v = torch.randn(B, frames, a.J, 2, device=dev, generator=gen)
+        ga = torch.full((B, frames, 384, 384, 2), float("nan"), device=dev)
+        gb = torch.full((B, frames, 384, 384, 2), float("nan"), device=dev)
+        for op, g in ((a, ga), (b, gb)):
+            _lib.check(L.nufft_spread(v.data_ptr(), B * frames, frames, C.byref(op._plan(v.device)), g.data_ptr(),
+                                      _lib.stream_of(v)), "nufft_spread")
+        assert torch.isfinite(ga).all()
+        assert torch.equal(ga, gb), "B = %d: %g" % (B, (ga - gb).abs().max().item())
+    if shared:
+        v = torch.randn(17, frames, a.J, 2, device=dev, generator=gen)
+        got = a._type1(v, 1.0)
+        assert torch.equal(got, b._type1(v, 1.0))
+        orc = NUDFTOracle(traj, 192)
+        assert_close(got[[0, 16]], orc.adjoint(v[[0, 16]].cpu()), RTOL, "type 1 at 17 chains")
