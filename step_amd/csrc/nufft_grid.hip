@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
 }
 
 // The same interpolation with the grid staged through LDS: a workgroup owns a 64 x 32 tile of
-// frame index t for NI_CH chains, loads the tile plus the W - 1 rows / columns a footprint that
+// frame index t for NI_CH chains (one), loads the tile plus the W - 1 rows / columns a footprint that
 // starts in it can reach (each grid point crosses HBM about 1.25 times instead of being gathered
 // 36 times through L2), then takes the samples whose footprint starts in the tile: the host has
 // binned them (every sample in exactly one tile) and laid their tables out in bin order, so a
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) void k_nufft_interp(const float2* __restrict__
 // loss_part[f][tile] = the tile's share of sum |yhat - y|^2.
 #define NI_TW 64             // tile width: 69-point row segments touch 5 lines of 128 bytes for 552 useful bytes
 #define NI_TH 32
-#define NI_CH 2
+#define NI_CH 1              // chains per workgroup (2: 291 us against 279; 23 KB of LDS and 66 registers leave room for six workgroups per CU)
 #define NI_SW (NI_TW + NU_WMAX - 1)
 #define NI_SH (NI_TH + NU_WMAX - 1)
-#define NI_BATCH 10          // rows a wave has in flight while staging
+#define NI_RB ((NI_SH + 3) / 4)   // staged rows per wave and chain
 __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __restrict__ grid, NuPlan p, int T, int B,
                                                             const float2* __restrict__ y, int y_batch,
                                                             float res_scale, float2* __restrict__ out,
@@ -182,55 +182,48 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
     };
     if (have) fetch();
     {
-        // A wave takes whole rows of the staged region (rows w, w + 4, ... of nc * sh): its lanes load the
-        // first 64 points of the row, NI_BATCH rows in flight before the first LDS store; the sw - 64 points
-        // beyond are taken eight to a row afterwards.  No division anywhere: the flat index this loop used to
+        // A wave takes whole rows of the staged region (rows w, w + 4, ... of every chain): its lanes load the
+        // first 64 points of the row, the sw - 64 points beyond are taken eight to a row; everything is in
+        // flight before the first LDS store.  No division anywhere: the flat index this loop used to
         // split into (chain, row, column) by run-time divisors cost 1800 vector instructions per wave and
         // made the kernel ALU-bound (77 % of the cycles) while it moved 2.7 TB/s.
-        const int wv = tid >> 6, lane = tid & 63, rows = nc * sh;
+        const int wv = tid >> 6, lane = tid & 63;
         const int gx0 = nu_wrap(tx * NI_TW + lane, G);
         const float2* gb = grid + ((size_t)b0 * T + t) * G * G;
         const size_t cstride = (size_t)T * G * G;
-        for (int r0 = wv; r0 < rows; r0 += 4 * NI_BATCH) {
-            float2 v[NI_BATCH];
+        static_assert(4 * NI_RB >= NI_SH && 64 >= NI_SH && NI_TW == 64 && NU_WMAX - 1 <= 8, "row split of the staging loop");
+        float2 v[NI_CH][NI_RB];
 #pragma unroll
-            for (int i = 0; i < NI_BATCH; ++i) {
-                const int r = r0 + 4 * i;
-                if (r < rows) {
-                    const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;             // NI_CH == 2
-                    v[i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx0];
-                }
-            }
+        for (int cc = 0; cc < NI_CH; ++cc)
 #pragma unroll
-            for (int i = 0; i < NI_BATCH; ++i) {
-                const int r = r0 + 4 * i;
-                if (r < rows) {
-                    const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
-                    s_g[cc][ry * sw + lane] = v[i];
-                }
+            for (int i = 0; i < NI_RB; ++i) {
+                const int ry = wv + 4 * i;
+                if (cc < nc && ry < sh) v[cc][i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx0];
             }
-        }
-        static_assert(NI_CH == 2 && NU_WMAX - 1 <= 8, "row split of the staging loop");
         const int rx = 64 + (tid & 7);
         const int gx1 = nu_wrap(tx * NI_TW + rx, G);
-        float2 v[3];
+        float2 v1[NI_CH][2];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = (tid >> 3) + 32 * i;
-            if (r < rows && rx < sw) {
-                const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
-                v[i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx1];
-            }
-        }
+        for (int cc = 0; cc < NI_CH; ++cc)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = (tid >> 3) + 32 * i;
-            if (r < rows && rx < sw) {
-                const int cc = r >= sh ? 1 : 0, ry = r - cc * sh;
-                s_g[cc][ry * sw + rx] = v[i];
+            for (int i = 0; i < 2; ++i) {
+                const int ry = (tid >> 3) + 32 * i;
+                if (cc < nc && ry < sh && rx < sw) v1[cc][i] = gb[cc * cstride + (size_t)nu_wrap(ty * NI_TH + ry, G) * G + gx1];
             }
-        }
-        static_assert(3 * 32 >= NI_CH * NI_SH, "the remainder pass covers every row");
+#pragma unroll
+        for (int cc = 0; cc < NI_CH; ++cc)
+#pragma unroll
+            for (int i = 0; i < NI_RB; ++i) {
+                const int ry = wv + 4 * i;
+                if (cc < nc && ry < sh) s_g[cc][ry * sw + lane] = v[cc][i];
+            }
+#pragma unroll
+        for (int cc = 0; cc < NI_CH; ++cc)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ry = (tid >> 3) + 32 * i;
+                if (cc < nc && ry < sh && rx < sw) s_g[cc][ry * sw + rx] = v1[cc][i];
+            }
     }
     __syncthreads();
     float acc = 0.f;
@@ -264,6 +257,10 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
         if (have) fetch();
     }
     if (loss_part) {
+#if NI_CH == 1
+        const float tot = block_sum(acc, red);                // a fixed tree: deterministic
+        if (tid == 0) loss_part[((size_t)b0 * T + t) * ntiles + tile] = tot;
+#else
         red[tid] = acc;
         __syncthreads();
         if (tid < nc) {                                       // thread c: its chain's partials, in slot order
@@ -271,6 +268,7 @@ __global__ __launch_bounds__(256) void k_nufft_interp_tiled(const float2* __rest
             for (int i = 0; i < nslot; ++i) sum += red[NI_CH * i + tid];
             loss_part[((size_t)(b0 + tid) * T + t) * ntiles + tile] = sum;
         }
+#endif
     }
 }
 
