@@ -374,6 +374,14 @@ typedef struct {
                                   -- in the order the kernel should take the tiles (longest lists first) */
     const int32_t* wide_ent;   /* sample ids, ascending within a tile (padding: any valid id) */
     const float* wide_w;       /* [entries][2][16] fp32 product wy[gy - iy0] * wx[gx - ix0] on the torus, 0 outside the footprint */
+    /* the six below may all be NULL (then nufft_fwd_interp is not available): every sample once, by the strip of 16
+     * grid columns that holds ix0 mod G, for the kernel that interpolates straight from the forward column pass */
+    const int32_t* strip_ptr;  /* [traj_frames][G/16 + 1] (CSR, per trajectory frame from 0) */
+    const int32_t* strip_ent;  /* [traj_frames][J] sample ids, ascending within a strip */
+    const int32_t* strip_x0;   /* [traj_frames][J] ix0 mod G, iy0 mod G and the weights in the order of strip_ent */
+    const int32_t* strip_y0;
+    const float* strip_wx;     /* [traj_frames][J][W] */
+    const float* strip_wy;
 } nufft_plan_t;
 
 int nufft_interp_blocks(int J);     /* partial sums per frame of the gathering kernel */
@@ -404,6 +412,17 @@ int nufft_fwd_grid(const float* x, int nframes, int T, const nufft_plan_t* plan,
 int nufft_inv_grid(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
                    const float* chain_scale, float out_scale, float* work_c64, float* out,
                    void* stream);
+
+/* nufft_fwd_grid + nufft_interp without the grid: the forward column pass keeps a strip of 16 + W - 1 grid
+ * columns in LDS and the samples whose footprint starts in the strip are interpolated from there (the
+ * oversampled grid is neither written nor read: per frame 0.8 MB instead of 3.2 MB through HBM).  Needs the
+ * plan's strip bins and R = 192; same arguments and results as nufft_interp (to fp32 rounding of the same sums),
+ * loss_part holds frames * nufft_fwd_interp_parts(plan) floats (0 parts = not available for this plan).
+ * NO REFERENCE COUNTERPART. */
+int nufft_fwd_interp_parts(const nufft_plan_t* plan);
+int nufft_fwd_interp(const float* x, int nframes, int T, const nufft_plan_t* plan, const float* y_c64,
+                     int y_batch, float res_scale, float* work_c64, float* out_c64, float* loss_part,
+                     float* loss, float* loss_total, void* stream);
 
 /* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in

@@ -47,7 +47,8 @@ class nufft_plan_t(C.Structure):
                 ("ix0", c_p), ("iy0", c_p), ("wx", c_p), ("wy", c_p), ("tile_ptr", c_p), ("tile_ent", c_p),
                 ("tile_base", c_p), ("apod", c_p), ("own_ptr", c_p), ("own_ent", c_p),
                 ("own_x0", c_p), ("own_y0", c_p), ("own_wx", c_p), ("own_wy", c_p),
-                ("wide_rec", c_p), ("wide_ent", c_p), ("wide_w", c_p)]
+                ("wide_rec", c_p), ("wide_ent", c_p), ("wide_w", c_p),
+                ("strip_ptr", c_p), ("strip_ent", c_p), ("strip_x0", c_p), ("strip_y0", c_p), ("strip_wx", c_p), ("strip_wy", c_p)]
 
 
 class mcmc_params_t(C.Structure):
@@ -110,6 +111,8 @@ SIGNATURES = {
     "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
     "nufft_grid_fft_supported": (c_i, [c_i, c_i]),
     "nufft_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
+    "nufft_fwd_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
+    "nufft_fwd_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "nufft_fwd_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p, c_p]),
     "nufft_inv_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p, c_p]),
     "mri_loss_grad_static": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,

@@ -73,3 +73,6 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
+
+// nufft_grid.hip: loss[b] = sum of a chain's per_chain partial sums in fixed order (used by nufft_fft.hip too)
+int nufft_loss_reduce(const float* loss_part, int B, int per_chain, float* loss, float* loss_total, void* stream);

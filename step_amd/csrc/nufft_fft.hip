@@ -93,6 +93,129 @@ __global__ __launch_bounds__(NF_CT) void k_nufft_fft_cols(const cf32* __restrict
     }
 }
 
+// The forward column pass and the interpolation in one kernel: the grid never reaches HBM.  A
+// workgroup owns a strip of 16 grid columns of one frame plus the W - 1 columns a footprint that starts
+// in the strip can reach (a third of the column transforms are done twice, but two workgroups share a CU), runs the two passes of
+// k_nufft_fft_cols<-1> on them, leaves the pass-B outputs in the exchange tile (thread (c, col) owns the
+// 24 slots 24 c + b it has just read: row c + 16 d goes to slot 24 c + d, no barrier in between) and then
+// takes the samples whose footprint starts in the strip -- binned by strip on the host, tables in bin
+// order like the owner bins of k_nufft_interp_tiled, the first sample's tables requested ahead of the
+// transforms.  Per frame 590 KB x (16 + W - 1) / 16 in instead of 590 KB in, 1.18 MB out and 1.47 MB in
+// again.  The 36 products are summed in the order of k_nufft_interp.
+#define NF_SC 16             // strip width: 74 KB of LDS, two workgroups per CU (32: one, 0.39 ms against 0.33)
+#define NF_ES (NF_SC + 7)     // slot stride of the exchange tile: NF_SC + 7 columns at most, odd
+struct NfStrips {
+    int W, J, traj_frames;
+    const int32_t* ptr;       // [traj_frames][G / NF_SC + 1]
+    const int32_t* ent;       // [traj_frames][J] sample ids by strip
+    const int32_t* x0;        // [traj_frames][J] first point (wrapped into [0, G)), in the order of ent
+    const int32_t* y0;
+    const float* wx;          // [traj_frames][J][W]
+    const float* wy;
+};
+__global__ __launch_bounds__(1024) void k_nufft_cols_interp(const cf32* __restrict__ in, NfStrips p, int T,
+                                                            const float2* __restrict__ y, int y_batch, float res_scale,
+                                                            float2* __restrict__ out, float* __restrict__ loss_part) {
+    extern __shared__ __attribute__((aligned(16))) cf32 nf_lds[];
+    __shared__ float red[16];
+    cf32* tw = nf_lds;                                        // [384]
+    cf32* E = nf_lds + NF_G;                                  // [384 slots][NF_ES]
+    const int W = p.W, ncol = NF_SC + W - 1, nthr = blockDim.x;
+    const int tid = threadIdx.x, q = tid / ncol, col = tid - q * ncol;
+    const int strip = blockIdx.x, f = blockIdx.y, t = f % T, b = f / T, tf = p.traj_frames == 1 ? 0 : t;
+    const int nstrips = NF_G / NF_SC;
+    // this thread's first sample: its tables travel under the transforms
+    const int32_t* ptr = p.ptr + (size_t)tf * (nstrips + 1);
+    const int e0 = ptr[strip], e1 = ptr[strip + 1];
+    const size_t tb = (size_t)tf * p.J;
+    int s = e0 + tid, j = 0, lx = 0, ly = 0;
+    bool have = s < e1;
+    float wxr[8], wyr[8];
+    float2 m = make_float2(0.f, 0.f);
+    auto fetch = [&]() {
+        j = p.ent[tb + s];
+        lx = p.x0[tb + s] - strip * NF_SC;
+        ly = p.y0[tb + s];
+        const float* wxp = p.wx + (tb + s) * W;
+        const float* wyp = p.wy + (tb + s) * W;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wxr[k] = k < W ? wxp[k] : 0.f;
+            wyr[k] = k < W ? wyp[k] : 0.f;
+        }
+        if (y) m = y[((size_t)(y_batch > 1 ? b : 0) * T + t) * p.J + j];
+    };
+    if (have) fetch();
+    int kx = strip * NF_SC + col;
+    kx = kx >= NF_G ? kx - NF_G : kx;
+    {
+        const int bq = q;                                     // pass-A task: grid rows 24 a + b (threads with q >= 24: none)
+        cf32 v[16];
+        if (q < 24) {
+            const cf32* src = in + (size_t)f * NF_R * NF_G + kx;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int n = 24 * a + bq;
+                v[a] = a < 4 ? src[(size_t)(n + NF_H) * NF_G]
+                             : (a >= 12 ? src[(size_t)(n - (NF_G - NF_H)) * NF_G] : c_make(0.f, 0.f));
+            }
+        }
+        nf_twiddles(tw, tid, nthr);
+        __syncthreads();                                      // barriers outside the role tests: a wave may hold both roles
+        if (q < 24) {
+            fft384_pass_a<-1>(v, bq, tw);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) E[(24 * c + bq) * NF_ES + col] = v[c];
+        }
+    }
+    __syncthreads();
+    if (q < 16) {
+        const int c = q;                                      // pass-B task: grid rows c + 16 d -> slots 24 c + d
+        cf32 u[24];
+#pragma unroll
+        for (int bb = 0; bb < 24; ++bb) u[bb] = E[(24 * c + bb) * NF_ES + col];
+        fft384_pass_b<-1>(u);
+#pragma unroll
+        for (int d = 0; d < 24; ++d) E[(24 * c + d) * NF_ES + col] = u[d];
+    }
+    __syncthreads();
+    float acc = 0.f;
+    while (have) {
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+            if (a < W) {
+                int gy = ly + a;
+                gy = gy >= NF_G ? gy - NF_G : gy;
+                const cf32* row = E + (24 * (gy & 15) + (gy >> 4)) * NF_ES + lx;
+                float rr = 0.f, ri = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < W) {
+                        const cf32 g = row[k];
+                        rr += wxr[k] * g.x;
+                        ri += wxr[k] * g.y;
+                    }
+                sr += wyr[a] * rr;
+                si += wyr[a] * ri;
+            }
+        float2 o = make_float2(sr, si);
+        if (y) {
+            const float dr = sr - m.x, di = si - m.y;
+            acc += dr * dr + di * di;
+            o = make_float2(res_scale * dr, res_scale * di);
+        }
+        out[(size_t)f * p.J + j] = o;
+        s += nthr;                                            // the strips through k = 0 hold more samples than threads
+        have = s < e1;
+        if (have) fetch();
+    }
+    if (loss_part) {
+        const float tot = block_sum(acc, red);
+        if (tid == 0) loss_part[(size_t)f * nstrips + strip] = tot;
+    }
+}
+
 // The two passes of NF_RW rows held in one LDS tile (row stride NF_RS): in place, natural order.
 // PRUNED_IN: only grid indices < 96 and >= 288 of a row hold data (the rest is taken as zero and
 // need not be initialised).
@@ -246,5 +369,44 @@ extern "C" int nufft_inv_grid(const float* grid_c64, int nframes, int T, const n
     hipLaunchKernelGGL(k_nufft_rows_inv, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st,
                        (const cf32*)work_c64, plan->apod, T, chain_scale, out_scale, out);
     STEP_CHECK_LAUNCH("nufft_inv_grid (rows)");
+    return STEP_OK;
+}
+
+// parts of loss_part per frame for nufft_fwd_interp, 0 if the plan has no strip bins
+extern "C" int nufft_fwd_interp_parts(const nufft_plan_t* plan) {
+    const bool ok = plan && plan->strip_ptr && plan->strip_ent && plan->strip_x0 && plan->strip_y0 && plan->strip_wx &&
+                    plan->strip_wy && plan->R == NF_R && plan->G == NF_G && plan->W >= 2 && plan->W <= 8;
+    return ok ? NF_G / NF_SC : 0;
+}
+
+extern "C" int nufft_fwd_interp(const float* x, int nframes, int T, const nufft_plan_t* plan, const float* y_c64,
+                                int y_batch, float res_scale, float* work_c64, float* out_c64, float* loss_part,
+                                float* loss, float* loss_total, void* stream) {
+    STEP_REQUIRE(x && work_c64 && out_c64, "nufft_fwd_interp: null pointer");
+    if (int rc = nf_check("nufft_fwd_interp", plan, nframes, T)) return rc;
+    const int parts = nufft_fwd_interp_parts(plan), B = nframes / T;
+    STEP_REQUIRE(parts > 0, "nufft_fwd_interp: the plan has no strip bins (or W = %d outside 2..8)", plan->W);
+    STEP_REQUIRE(plan->traj_frames == 1 || plan->traj_frames == T, "nufft_fwd_interp: traj_frames = %d must be 1 or T = %d",
+                 plan->traj_frames, T);
+    STEP_REQUIRE(!y_c64 || y_batch == 1 || y_batch == B, "nufft_fwd_interp: measurement batch %d vs B=%d", y_batch, B);
+    STEP_REQUIRE(!loss || (y_c64 && loss_part), "nufft_fwd_interp: the loss needs the measurement and loss_part");
+    STEP_REQUIRE(!loss_total || loss, "nufft_fwd_interp: loss_total needs loss");
+    hipStream_t st = (hipStream_t)stream;
+    step_allow_lds((const void*)k_nufft_rows_fwd, NF_LDS_ROWS);
+    hipLaunchKernelGGL(k_nufft_rows_fwd, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st, x, plan->apod,
+                       (cf32*)work_c64);
+    STEP_CHECK_LAUNCH("nufft_fwd_interp (rows)");
+    const size_t lds = (size_t)(NF_G + NF_G * NF_ES) * sizeof(cf32);
+    const int threads = (24 * (NF_SC + plan->W - 1) + 63) / 64 * 64;
+    step_allow_lds((const void*)k_nufft_cols_interp, lds);
+    const NfStrips sp{plan->W, plan->J, plan->traj_frames, plan->strip_ptr, plan->strip_ent, plan->strip_x0,
+                      plan->strip_y0, plan->strip_wx, plan->strip_wy};
+    STEP_REQUIRE(nframes <= 65535, "nufft_fwd_interp: %d frames exceed the grid", nframes);
+    hipLaunchKernelGGL(k_nufft_cols_interp, dim3(parts, nframes), dim3(threads), lds, st, (const cf32*)work_c64, sp, T,
+                       (const float2*)y_c64, y_batch, res_scale, (float2*)out_c64, y_c64 ? loss_part : nullptr);
+    STEP_CHECK_LAUNCH("nufft_fwd_interp (columns + interpolation)");
+    if (loss) {
+        if (int rc = nufft_loss_reduce(loss_part, B, T * parts, loss, loss_total, stream)) return rc;
+    }
     return STEP_OK;
 }

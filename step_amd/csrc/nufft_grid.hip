@@ -523,6 +523,15 @@ extern "C" int nufft_interp_parts(const nufft_plan_t* plan) {
     return nu_tiled(plan) ? (plan->G / NI_TW) * (plan->G / NI_TH) : nufft_interp_blocks(plan->J);
 }
 
+// loss[b] = sum of the chain's per_chain partial sums (fixed order), loss_total = their sum (may be NULL)
+int nufft_loss_reduce(const float* loss_part, int B, int per_chain, float* loss, float* loss_total, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_nufft_loss_finish, dim3(B), dim3(256), 0, st, loss_part, per_chain, loss);
+    if (loss_total) hipLaunchKernelGGL(k_nufft_loss_total, dim3(1), dim3(64), 0, st, loss, B, loss_total);
+    STEP_CHECK_LAUNCH("nufft loss reduction");
+    return STEP_OK;
+}
+
 extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
                             const float* y_c64, int y_batch, float res_scale, float* out_c64,
                             float* loss_part, float* loss, float* loss_total, void* stream) {
@@ -545,11 +554,7 @@ extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nuf
                            y_c64 ? loss_part : nullptr);
     }
     STEP_CHECK_LAUNCH("nufft_interp");
-    if (loss) {
-        hipLaunchKernelGGL(k_nufft_loss_finish, dim3(B), dim3(256), 0, st, loss_part, T * parts, loss);
-        if (loss_total) hipLaunchKernelGGL(k_nufft_loss_total, dim3(1), dim3(64), 0, st, loss, B, loss_total);
-        STEP_CHECK_LAUNCH("nufft_interp (loss)");
-    }
+    if (loss) return nufft_loss_reduce(loss_part, B, T * parts, loss, loss_total, stream);
     return STEP_OK;
 }
 

@@ -31,6 +31,7 @@ __all__ = ["RadialMRI", "golden_angle_radial", "kb_plan"]
 _TW, _TH = 16, 4                    # tile of a wave of the spread kernel (nufft_grid.hip)
 _OWN_TW, _OWN_TH = 64, 32           # tile of the interpolation kernel (NI_TW, NI_TH in nufft_grid.hip)
 _WIDE_TW, _WIDE_TH, _WIDE_PAD = 16, 2, 4     # tile and list padding of the lane-per-chain spread kernel (NW_*)
+_STRIP = 16                         # columns per strip of the fused column pass + interpolation (NF_SC in nufft_fft.hip)
 
 
 def golden_angle_radial(frames, spokes, resolution):
@@ -136,13 +137,27 @@ def kb_plan(kappa, R, W=6):
         take = lambda a: np.take_along_axis(a, own_ent.astype(np.int64).reshape(own_ent.shape + (1,) * (a.ndim - 2)), axis=1)
         own_x0, own_y0 = take((i0[..., 0] % G).astype(np.int32)), take((i0[..., 1] % G).astype(np.int32))
         own_wx, own_wy = take(w[:, :, 0].astype(np.float32)), take(w[:, :, 1].astype(np.float32))
+    # every sample once more, by the strip of 16 grid columns in which its footprint starts (the fused column
+    # pass + interpolation of nufft_fft.hip keeps that strip and the W - 1 columns beyond it in LDS)
+    strips = dict(strip_ptr=None, strip_ent=None, strip_x0=None, strip_y0=None, strip_wx=None, strip_wy=None)
+    if G % _STRIP == 0:
+        ns = G // _STRIP
+        skey = (i0[..., 0] % G) // _STRIP                                                  # [Tt, J]
+        sent = np.argsort(skey, axis=1, kind="stable").astype(np.int32)
+        sptr = np.zeros((Tt, ns + 1), np.int32)
+        for t in range(Tt):
+            sptr[t, 1:] = np.cumsum(np.bincount(skey[t], minlength=ns))
+        stake = lambda a: np.take_along_axis(a, sent.astype(np.int64).reshape(sent.shape + (1,) * (a.ndim - 2)), axis=1)
+        strips = dict(strip_ptr=sptr, strip_ent=sent,
+                      strip_x0=stake((i0[..., 0] % G).astype(np.int32)), strip_y0=stake((i0[..., 1] % G).astype(np.int32)),
+                      strip_wx=stake(w[:, :, 0].astype(np.float32)), strip_wy=stake(w[:, :, 1].astype(np.float32)))
     # continuous transform of the kernel at nu = (n - R/2) / G cycles per grid sample
     d = np.linspace(-W / 2.0, W / 2.0, 4001)
     nu = (np.arange(R) - R / 2) / G
     phat = np.trapezoid(_kb(d, W, beta)[None, :] * np.cos(2 * math.pi * nu[:, None] * d[None, :]), d, axis=1)
     wide = _wide_lists(i0, w.astype(np.float32), G, W) if G % _WIDE_TW == 0 else \
         dict(wide_rec=None, wide_ent=None, wide_w=None)
-    return dict(**wide, R=R, G=G, W=W, J=J, traj_frames=Tt,
+    return dict(**wide, **strips, R=R, G=G, W=W, J=J, traj_frames=Tt,
                 ix0=i0[..., 0].astype(np.int32), iy0=i0[..., 1].astype(np.int32),
                 wx=w[:, :, 0].astype(np.float32), wy=w[:, :, 1].astype(np.float32),
                 tile_ptr=np.stack(ptrs), tile_ent=np.concatenate(ents), tile_base=np.array(base[:-1], np.int64),
@@ -198,6 +213,7 @@ class RadialMRI(Operator):
         self.J = self._host["J"]
         self.max_chunk = max_chunk        # chains per pass: the oversampled grids are 8 G^2 bytes per frame
         self.grid_fft = 'auto'            # 'auto' | 'fused' (nufft_fft.hip) | 'library' (torch.fft around pad / crop)
+        self.fwd_interp = 'auto'          # 'auto' | 'fused' (column pass + interpolation in one kernel, no grid) | 'grid'
         self._dev = {}
 
     _prof = None
@@ -207,7 +223,8 @@ class RadialMRI(Operator):
         if key not in self._dev:
             h = self._host
             names = ("ix0", "iy0", "wx", "wy", "tile_ptr", "tile_ent", "tile_base", "apod", "own_ptr", "own_ent",
-                     "own_x0", "own_y0", "own_wx", "own_wy", "wide_rec", "wide_ent", "wide_w")
+                     "own_x0", "own_y0", "own_wx", "own_wy", "wide_rec", "wide_ent", "wide_w",
+                     "strip_ptr", "strip_ent", "strip_x0", "strip_y0", "strip_wx", "strip_wy")
             t = {k: torch.from_numpy(np.ascontiguousarray(h[k])).to(device) for k in names if h[k] is not None}
             plan = _lib.nufft_plan_t(h["R"], h["G"], h["W"], h["J"], h["traj_frames"],
                                      *[t[k].data_ptr() if k in t else None for k in names])
@@ -225,6 +242,37 @@ class RadialMRI(Operator):
         pad / crop kernels around a library FFT2."""
         return self.grid_fft == 'fused' or (self.grid_fft == 'auto'
                                             and bool(_lib.lib().nufft_grid_fft_supported(self.resolution, 2 * self.resolution)))
+
+    def _fused_fwd(self, device):
+        """nufft_fwd_interp (nufft_fft.hip): the forward column pass interpolates from its own LDS strip;
+        needs the own transforms (R = 192) and the plan's strip bins."""
+        if self.fwd_interp == 'grid' or not self._own_fft():
+            return 0
+        parts = _lib.lib().nufft_fwd_interp_parts(C.byref(self._plan(device)))
+        if self.fwd_interp == 'fused' and not parts:
+            raise RuntimeError("mri_radial: the fused forward needs R = 192 and the plan's strip bins")
+        return parts
+
+    def _samples(self, xc, yc, res_scale, out, part, loss):
+        """type 2 of a chunk: samples (yc None) or res_scale * (samples - yc) into ``out``, the per-chain
+        loss into ``loss``; -> the oversampled grid when one was made (else None)."""
+        n, T, dev = xc.shape[0], self.frames, xc.device
+        L, plan, st = _lib.lib(), self._plan(dev), _lib.stream_of(xc)
+        ya = (None, 1) if yc is None else (yc.data_ptr(), yc.shape[0])
+        if self._fused_fwd(dev):
+            work = torch.empty(n, T, self.resolution, 2 * self.resolution, device=dev, dtype=torch.complex64)
+            rc = L.nufft_fwd_interp(xc.data_ptr(), n * T, T, C.byref(plan), ya[0], ya[1], res_scale, work.data_ptr(),
+                                    out.data_ptr(), _lib.ptr(part), _lib.ptr(loss), None, st)
+            _lib.check(rc, "nufft_fwd_interp")
+            return None
+        Xg = self._grid_fft(xc)
+        rc = L.nufft_interp(Xg.data_ptr(), n * T, T, C.byref(plan), ya[0], ya[1], res_scale, out.data_ptr(),
+                            _lib.ptr(part), _lib.ptr(loss), None, st)
+        _lib.check(rc, "nufft_interp")
+        return Xg
+
+    def _parts(self, device):
+        return self._fused_fwd(device) or _lib.lib().nufft_interp_parts(C.byref(self._plan(device)))
 
     def _grid_fft(self, x):
         """pad + de-apodise -> FFT2 on the oversampled grid: [B, T, G, G] complex64."""
@@ -247,12 +295,8 @@ class RadialMRI(Operator):
         outs = []
         for i in range(0, x.shape[0], self.max_chunk):
             xc = x[i:i + self.max_chunk]
-            Xg = self._grid_fft(xc)
             out = torch.empty(xc.shape[0], self.frames, self.J, 2, device=x.device, dtype=torch.float32)
-            rc = _lib.lib().nufft_interp(Xg.data_ptr(), xc.shape[0] * self.frames, self.frames,
-                                         C.byref(self._plan(x.device)), None, 1, 1.0, out.data_ptr(), None,
-                                         None, None, _lib.stream_of(x))
-            _lib.check(rc, "nufft_interp")
+            self._samples(xc, None, 1.0, out, None, None)
             outs.append(out)
         return torch.cat(outs) if len(outs) > 1 else outs[0]
 
@@ -286,8 +330,7 @@ class RadialMRI(Operator):
         y = y.detach().to(device=dev, dtype=torch.float32).contiguous()
         if y.dim() != 4 or tuple(y.shape[1:]) != (T, self.J, 2) or y.shape[0] not in (1, B):
             raise ValueError("measurement shape %s, expected [1 or %d, %d, %d, 2]" % (tuple(y.shape), B, T, self.J))
-        L, plan, st = _lib.lib(), self._plan(dev), _lib.stream_of(x)
-        nblk = L.nufft_interp_parts(C.byref(plan))
+        nblk = self._parts(dev)
         loss = torch.empty(B, device=dev, dtype=torch.float32)
         grad = torch.empty_like(x) if need_grad else None
         t0 = None
@@ -297,13 +340,10 @@ class RadialMRI(Operator):
         for i in range(0, B, self.max_chunk):
             xc = x[i:i + self.max_chunk]
             n = xc.shape[0]
-            Xg = self._grid_fft(xc)
             res = torch.empty(n, T, self.J, 2, device=dev, dtype=torch.float32)
             part = torch.empty(n * T * nblk, device=dev, dtype=torch.float32)
             yc = y if y.shape[0] == 1 else y[i:i + n]
-            rc = L.nufft_interp(Xg.data_ptr(), n * T, T, C.byref(plan), yc.data_ptr(), yc.shape[0], 2.0,
-                                res.data_ptr(), part.data_ptr(), loss[i:i + n].data_ptr(), None, st)
-            _lib.check(rc, "nufft_interp")
+            Xg = self._samples(xc, yc, 2.0, res, part, loss[i:i + n])
             if need_grad:
                 del Xg
                 self._type1(res, 1.0, out=grad[i:i + n])

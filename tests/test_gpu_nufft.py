@@ -190,3 +190,30 @@ def test_lane_per_chain_spread_equals_the_tile_kernel(shared, dev):
         assert torch.equal(got, b._type1(v, 1.0))
         orc = NUDFTOracle(traj, 192)
         assert_close(got[[0, 16]], orc.adjoint(v[[0, 16]].cpu()), RTOL, "type 1 at 17 chains")
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_fused_column_pass_and_interpolation_equals_the_grid_route(shared, dev):
+    """nufft_fwd_interp (the forward column pass interpolates from its own LDS strip, no grid in HBM)
+    against nufft_fwd_grid + nufft_interp: the same sums over the same transformed values, to fp32
+    rounding; footprints that wrap in x (the last strip reaches into strip 0) and in y."""
+    from step_amd.forward_operator import golden_angle_radial
+    traj = golden_angle_radial(1 if shared else 12, 24, 192)
+    rng = np.random.RandomState(6)
+    extra = rng.uniform(-96, 96, (traj.shape[0], 700, 2))
+    extra[:, :5] = [[-96, -96], [96, 96], [-96, 95.99], [0, 0], [95.2, -0.3]]
+    traj = np.concatenate([traj, extra], axis=1)
+    a, b = make(spokes=24, frames=12, trajectory=traj), make(spokes=24, frames=12, trajectory=traj)
+    a.fwd_interp, b.fwd_interp = "fused", "grid"
+    assert a._fused_fwd(dev) == 24 and b._fused_fwd(dev) == 0
+    gen = torch.Generator(device=dev).manual_seed(13)
+    x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
+    ya = a(x)
+    assert_close(ya, b(x), 2e-6, "samples")
+    y = ya[:1] + 0.1 * torch.randn(1, 12, a.J, 2, device=dev, generator=gen)
+    (ga, la), (gb, lb) = a.gradient(x, y, return_loss=True), b.gradient(x, y, return_loss=True)
+    assert_close(la, lb, 2e-6, "loss")
+    assert_close(ga, gb, 2e-6, "gradient")
+    yb = ya + 0.1 * torch.randn(ya.shape, device=dev, generator=gen)             # a measurement per chain
+    assert_close(a.loss(x, yb), b.loss(x, yb), 2e-6, "per-chain loss, per-chain measurement")
+    assert torch.equal(a.gradient(x, y), ga)
