@@ -12,10 +12,11 @@ with kappa in cycles per field of view.  Same operator interface as the other ta
 (``__call__``, ``loss``, ``gradient``, autograd through ``loss``); registry name ``'mri_radial'``.
 The default trajectory is golden-angle radial: ``spokes`` spokes of ``R`` read-out points per
 frame, the angle advancing by pi (sqrt(5) - 1) / 2 from spoke to spoke across the frames.
-Hand-written: the interpolation (+ residual + loss; 32 x 32 grid tiles through LDS), the
-spread (a deterministic gather over host-binned tiles) and, for R = 192, the oversampled-grid
-transforms themselves (nufft_fft.hip: 384-point passes fused with pad / crop / de-apodisation and
-pruned to the rows that are not zero).  Other sizes: pad and crop kernels around hipFFT through
+Hand-written: the interpolation (+ residual + loss; grid tiles through LDS), the spread (a
+deterministic gather over host-binned tiles; from 16 chains on with a lane per chain) and, for
+R = 192, the oversampled-grid transforms themselves (nufft_fft.hip: 384-point passes fused with
+pad / crop / de-apodisation and pruned to the rows that are not zero), the forward column pass
+interpolating straight from its LDS strip (``fwd_interp = 'grid'`` forces the grid route).  Other sizes: pad and crop kernels around hipFFT through
 ``torch.fft`` on the same stream (``grid_fft = 'library'`` forces that route)."""
 import ctypes as C
 import math
