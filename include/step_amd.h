@@ -369,7 +369,7 @@ typedef struct {
      * the samples touching each 16 (x) by 2 (y) grid tile with their weights AT THE TILE'S POINTS, for the
      * spread kernel that gives every chain a lane (used from 16 chains on; bit-identical for finite input) */
     const int32_t* wide_rec;   /* [traj_frames][(G/16)(G/2)][16]: tile (row-major id), its first entry in wide_ent /
-                                  wide_w, its entries (a multiple of 4: padded with zero-weight entries), 0, the
+                                  wide_w, its entries (a multiple of 4: padded with zero-weight entries), `outside` (see nufft_adjoint; 0 if unused), the
                                   sample ids of its first 8 entries (any valid id where the list is shorter), 0 x 4
                                   -- in the order the kernel should take the tiles (longest lists first) */
     const int32_t* wide_ent;   /* sample ids, ascending within a tile (padding: any valid id) */
@@ -423,6 +423,18 @@ int nufft_fwd_interp_parts(const nufft_plan_t* plan);
 int nufft_fwd_interp(const float* x, int nframes, int T, const nufft_plan_t* plan, const float* y_c64,
                      int y_batch, float res_scale, float* work_c64, float* out_c64, float* loss_part,
                      float* loss, float* loss_total, void* stream);
+
+/* nufft_spread + nufft_inv_grid (type 1: samples -> image) for R = 192 with the lane-per-chain lists, from 16
+ * chains on (nufft_adjoint_supported), skipping what holds nothing: `range_host` is a HOST array
+ * [traj_frames][G/16][2] of bounds (lo, hi) on the centred tile-row coordinate (grid row >> 1, minus 192 from
+ * 96 on) outside which no sample reaches the 16-column tile column; tiles whose wide_rec record carries
+ * `outside` = 1 (4th int; must mean: outside these bounds) are not written by the spread and not read by the
+ * inverse column pass (a radial trajectory leaves 21 % of the grid empty).  grid_c64: scratch of nframes * G * G
+ * complex64, work_c64 as for nufft_inv_grid.  Same result as the two calls.  NO REFERENCE COUNTERPART. */
+int nufft_adjoint_supported(const nufft_plan_t* plan, int B);
+int nufft_adjoint(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan,
+                  const int32_t* range_host, const float* chain_scale, float out_scale, float* grid_c64,
+                  float* work_c64, float* out, void* stream);
 
 /* mri_loss_grad without a workspace argument, for callers that cannot allocate: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in

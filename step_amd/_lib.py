@@ -111,6 +111,8 @@ SIGNATURES = {
     "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
     "nufft_grid_fft_supported": (c_i, [c_i, c_i]),
     "nufft_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
+    "nufft_adjoint_supported": (c_i, [C.POINTER(nufft_plan_t), c_i]),
+    "nufft_adjoint": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "nufft_fwd_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
     "nufft_fwd_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "nufft_fwd_grid": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p, c_p]),

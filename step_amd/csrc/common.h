@@ -76,3 +76,6 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // nufft_grid.hip: loss[b] = sum of a chain's per_chain partial sums in fixed order (used by nufft_fft.hip too)
 int nufft_loss_reduce(const float* loss_part, int B, int per_chain, float* loss, float* loss_total, void* stream);
+// nufft_grid.hip: nufft_spread with the option of leaving the tiles outside the column ranges unwritten
+int nufft_spread_impl(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,
+                      int skip_outside, void* stream);

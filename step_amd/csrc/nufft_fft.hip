@@ -41,8 +41,19 @@ __device__ __forceinline__ void nf_twiddles(cf32* tw, int tid, int nthreads) {
 
 // SIGN = -1: in = T [f][R][G] (image rows), out = grid [f][G][G]
 // SIGN = +1: in = grid [f][G][G], out = T [f][R][G] (image rows), unnormalised
+// rows of a 16-column tile column that can hold anything, as bounds on the centred tile-row coordinate
+// (row >> 1, minus 192 from 96 on), packed (lo & 0xffff) | (hi << 16) per (trajectory frame, tile column):
+// by value in the kernel arguments, so that the bounds cost no trip to memory ahead of the loads
+#define NF_RANGE_FRAMES 12
+struct NfRange {
+    int frames;                                               // 0: no bounds (every row is read)
+    int T;
+    int v[NF_RANGE_FRAMES * (NF_G / 16)];
+};
+
 template <int SIGN>
-__global__ __launch_bounds__(NF_CT) void k_nufft_fft_cols(const cf32* __restrict__ in, cf32* __restrict__ out) {
+__global__ __launch_bounds__(NF_CT) void k_nufft_fft_cols(const cf32* __restrict__ in, cf32* __restrict__ out,
+                                                          const NfRange rg) {
     extern __shared__ __attribute__((aligned(16))) cf32 nf_lds[];
     cf32* tw = nf_lds;                                        // [384]
     cf32* E = nf_lds + NF_G;                                  // [384 slots][32 columns]
@@ -61,8 +72,18 @@ __global__ __launch_bounds__(NF_CT) void k_nufft_fft_cols(const cf32* __restrict
             }
         } else {
             const cf32* src = in + (size_t)f * NF_G * NF_G + kx;
+            int lo = -32768, hi = 32767;
+            if (rg.frames) {                                  // nufft_adjoint: the spread left the rows outside unwritten
+                const int tf = rg.frames == 1 ? 0 : f % rg.T;
+                const int pk = rg.v[tf * (NF_G / 16) + (kx >> 4)];
+                lo = (short)(pk & 0xffff);
+                hi = pk >> 16;
+            }
 #pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = src[(size_t)(24 * a + b) * NF_G];
+            for (int a = 0; a < 16; ++a) {
+                const int tr = (24 * a + b) >> 1, cr = tr < NF_G / 4 ? tr : tr - NF_G / 2;
+                v[a] = (cr >= lo && cr <= hi) ? src[(size_t)(24 * a + b) * NF_G] : c_make(0.f, 0.f);
+            }
         }
         nf_twiddles(tw, tid, NF_CT);
         __syncthreads();
@@ -350,8 +371,23 @@ extern "C" int nufft_fwd_grid(const float* x, int nframes, int T, const nufft_pl
     STEP_CHECK_LAUNCH("nufft_fwd_grid (rows)");
     step_allow_lds((const void*)k_nufft_fft_cols<-1>, NF_LDS_COLS);
     hipLaunchKernelGGL((k_nufft_fft_cols<-1>), dim3(NF_G / NF_CW, nframes), dim3(NF_CT), NF_LDS_COLS, st,
-                       (const cf32*)work_c64, (cf32*)grid_c64);
+                       (const cf32*)work_c64, (cf32*)grid_c64, NfRange{});
     STEP_CHECK_LAUNCH("nufft_fwd_grid (columns)");
+    return STEP_OK;
+}
+
+static int nf_inv_grid(const char* who, const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,
+                       const float* chain_scale, float out_scale, float* work_c64, float* out, const NfRange& rg,
+                       void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    step_allow_lds((const void*)k_nufft_fft_cols<1>, NF_LDS_COLS);
+    hipLaunchKernelGGL((k_nufft_fft_cols<1>), dim3(NF_G / NF_CW, nframes), dim3(NF_CT), NF_LDS_COLS, st,
+                       (const cf32*)grid_c64, (cf32*)work_c64, rg);
+    STEP_CHECK_LAUNCH(who);
+    step_allow_lds((const void*)k_nufft_rows_inv, NF_LDS_ROWS);
+    hipLaunchKernelGGL(k_nufft_rows_inv, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st,
+                       (const cf32*)work_c64, plan->apod, T, chain_scale, out_scale, out);
+    STEP_CHECK_LAUNCH(who);
     return STEP_OK;
 }
 
@@ -360,16 +396,34 @@ extern "C" int nufft_inv_grid(const float* grid_c64, int nframes, int T, const n
                               void* stream) {
     STEP_REQUIRE(grid_c64 && work_c64 && out, "nufft_inv_grid: null pointer");
     if (int rc = nf_check("nufft_inv_grid", plan, nframes, T)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    step_allow_lds((const void*)k_nufft_fft_cols<1>, NF_LDS_COLS);
-    hipLaunchKernelGGL((k_nufft_fft_cols<1>), dim3(NF_G / NF_CW, nframes), dim3(NF_CT), NF_LDS_COLS, st,
-                       (const cf32*)grid_c64, (cf32*)work_c64);
-    STEP_CHECK_LAUNCH("nufft_inv_grid (columns)");
-    step_allow_lds((const void*)k_nufft_rows_inv, NF_LDS_ROWS);
-    hipLaunchKernelGGL(k_nufft_rows_inv, dim3(NF_R / NF_RW, nframes), dim3(NF_RT), NF_LDS_ROWS, st,
-                       (const cf32*)work_c64, plan->apod, T, chain_scale, out_scale, out);
-    STEP_CHECK_LAUNCH("nufft_inv_grid (rows)");
-    return STEP_OK;
+    return nf_inv_grid("nufft_inv_grid", grid_c64, nframes, T, plan, chain_scale, out_scale, work_c64, out, NfRange{}, stream);
+}
+
+extern "C" int nufft_adjoint_supported(const nufft_plan_t* plan, int B) {
+    return plan && plan->R == NF_R && plan->G == NF_G && plan->wide_rec && plan->wide_ent && plan->wide_w && B >= 16 &&
+           plan->traj_frames >= 1 && plan->traj_frames <= NF_RANGE_FRAMES;
+}
+
+extern "C" int nufft_adjoint(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan,
+                             const int32_t* range_host, const float* chain_scale, float out_scale, float* grid_c64,
+                             float* work_c64, float* out, void* stream) {
+    STEP_REQUIRE(vals_c64 && range_host && grid_c64 && work_c64 && out, "nufft_adjoint: null pointer");
+    if (int rc = nf_check("nufft_adjoint", plan, nframes, T)) return rc;
+    STEP_REQUIRE(nufft_adjoint_supported(plan, nframes / T),
+                 "nufft_adjoint: needs R = %d, the lane-per-chain lists, at least 16 chains and at most %d trajectory frames",
+                 NF_R, NF_RANGE_FRAMES);
+    STEP_REQUIRE(plan->traj_frames == 1 || plan->traj_frames == T, "nufft_adjoint: traj_frames = %d must be 1 or T = %d",
+                 plan->traj_frames, T);
+    NfRange rg;
+    rg.frames = plan->traj_frames;
+    rg.T = T;
+    for (int i = 0; i < plan->traj_frames * (NF_G / 16); ++i) {
+        const int lo = range_host[2 * i], hi = range_host[2 * i + 1];
+        STEP_REQUIRE(lo >= -NF_G / 4 && lo <= NF_G / 4 && hi >= -NF_G / 4 && hi <= NF_G / 4, "nufft_adjoint: range %d = [%d, %d]", i, lo, hi);
+        rg.v[i] = (lo & 0xffff) | (hi << 16);
+    }
+    if (int rc = nufft_spread_impl(vals_c64, nframes, T, plan, grid_c64, 1, stream)) return rc;
+    return nf_inv_grid("nufft_adjoint", grid_c64, nframes, T, plan, chain_scale, out_scale, work_c64, out, rg, stream);
 }
 
 // parts of loss_part per frame for nufft_fwd_interp, 0 if the plan has no strip bins

@@ -42,7 +42,7 @@ struct NuPlan {
     const float* own_wx;                      // [traj_frames][J][W]
     const float* own_wy;
     int wide_tiles;                           // (G / 16) x (G / 2) tiles of 16 x 2 points (k_nufft_spread_wide), or 0
-    const int32_t* wide_rec;                  // [traj_frames][wide_tiles][16] (tile, first entry, entries, 0, first 8 ids, 0 x 4) in launch order
+    const int32_t* wide_rec;                  // [traj_frames][wide_tiles][16] (tile, first entry, entries, outside, first 8 ids, 0 x 4) in launch order
     const int32_t* wide_ent;                  // sample ids, ascending per tile, lists padded to multiples of 4
     const float* wide_w;                      // [entries][2][16] weight of the entry's sample at each point of its tile
 };
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
 #define NW_LS (NW_RP + 1)
 #define NW_MIN_CHAINS 16
 __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restrict__ vals, NuPlan p, int T, int B,
-                                                          float2* __restrict__ grid) {
+                                                          int skip_outside, float2* __restrict__ grid) {
     __shared__ float2 s_tr[64 * NW_LS];
     const int lane = threadIdx.x;
     const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * 64, tf = p.traj_frames == 1 ? 0 : t;
@@ -386,6 +386,7 @@ __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restri
     const int32_t* __restrict__ rp = p.wide_rec + ((size_t)tf * p.wide_tiles + blockIdx.x) * NW_REC;
     const int4 rec = *(const int4*)rp;
     const int4 ja = *(const int4*)(rp + 4), jb = *(const int4*)(rp + 8);
+    if (skip_outside && rec.w) return;                        // nufft_adjoint: nobody reads the tiles outside the column ranges
     const int32_t* __restrict__ ent = p.wide_ent;
     const float* __restrict__ wts = p.wide_w;
     const float2* __restrict__ v = vals + ((size_t)(b0 + min(lane, nc - 1)) * T + t) * p.J;
@@ -558,8 +559,10 @@ extern "C" int nufft_interp(const float* grid_c64, int nframes, int T, const nuf
     return STEP_OK;
 }
 
-extern "C" int nufft_spread(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan,
-                            float* grid_c64, void* stream) {
+// skip_outside: leave the tiles whose record says "outside the column ranges" unwritten (nufft_adjoint,
+// whose column pass does not read them); needs the lane-per-chain lists and B >= 16, else STEP_E_INVALID
+int nufft_spread_impl(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan, float* grid_c64,
+                      int skip_outside, void* stream) {
     STEP_REQUIRE(vals_c64 && grid_c64, "nufft_spread: null pointer");
     if (int rc = nu_check("nufft_spread", plan, nframes, T)) return rc;
     const NuPlan p = nu_plan(plan);
@@ -568,15 +571,21 @@ extern "C" int nufft_spread(const float* vals_c64, int nframes, int T, const nuf
         const int ny = T * ((B + 63) / 64);
         STEP_REQUIRE(p.G % NW_TW == 0 && ny <= 65535, "nufft_spread: G = %d, %d chains x %d frames", p.G, B, T);
         hipLaunchKernelGGL(k_nufft_spread_wide, dim3(p.wide_tiles, ny), dim3(64), 0, (hipStream_t)stream,
-                           (const float2*)vals_c64, p, T, B, (float2*)grid_c64);
+                           (const float2*)vals_c64, p, T, B, skip_outside, (float2*)grid_c64);
         STEP_CHECK_LAUNCH("nufft_spread (wide)");
         return STEP_OK;
     }
+    STEP_REQUIRE(!skip_outside, "nufft_adjoint: needs the plan's lane-per-chain lists and at least %d chains", NW_MIN_CHAINS);
     hipLaunchKernelGGL(k_nufft_spread, dim3((p.G / NU_TILE) * (p.G / NU_TILE), T * ((B + NU_CH - 1) / NU_CH)),
                        dim3(256), 0, (hipStream_t)stream, (const float2*)vals_c64, p, T, B,
                        (float2*)grid_c64);
     STEP_CHECK_LAUNCH("nufft_spread");
     return STEP_OK;
+}
+
+extern "C" int nufft_spread(const float* vals_c64, int nframes, int T, const nufft_plan_t* plan,
+                            float* grid_c64, void* stream) {
+    return nufft_spread_impl(vals_c64, nframes, T, plan, grid_c64, 0, stream);
 }
 
 extern "C" int nufft_crop_apod(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,

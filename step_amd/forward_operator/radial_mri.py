@@ -55,11 +55,11 @@ def _wide_lists(i0, w32, G, W):
     trajectory frame the samples touching each 16 x 2 grid tile, ascending, every list padded to a
     multiple of 4 with zero-weight entries; per entry the fp32 product wy * wx at each of the tile's
     32 points (zero outside the sample's footprint); per trajectory frame the records (tile, first
-    entry, entries, 0, ids of the first 8 entries, 0 x 4) by falling list length -- the order in which the kernel's waves take them."""
+    entry, entries, outside, ids of the first 8 entries, 0 x 4) by falling list length -- the order in which the kernel's waves take them."""
     Tt, J = i0.shape[:2]
     ntx, ntiles = G // _WIDE_TW, (G // _WIDE_TW) * (G // _WIDE_TH)
     k = np.arange(W)
-    recs, ents, wts, base = [], [], [], 0
+    recs, ents, wts, ranges, base = [], [], [], [], 0
     for t in range(Tt):
         x0, y0 = i0[t, :, 0] % G, i0[t, :, 1] % G
         tx = ((x0[:, None] + k) % G) // _WIDE_TW                   # [J, W] tile column of every footprint column
@@ -83,13 +83,25 @@ def _wide_lists(i0, w32, G, W):
         order = np.argsort(-cnt, kind="stable")
         rec = np.zeros((ntiles, 16), np.int32)
         rec[:, 0], rec[:, 1], rec[:, 2] = order, base + ptr[:-1][order], padded[order]
+        # per tile column the bounds on the centred tile-row coordinate outside which every list is empty
+        # (nufft_adjoint neither writes nor reads those tiles); rec[:, 3] = 1 for the tiles outside
+        nty = ntiles // ntx
+        cr = np.arange(nty)
+        cr = np.where(cr < nty // 2, cr, cr - nty)
+        full = cnt.reshape(nty, ntx) > 0
+        lo = np.where(full.any(0), np.where(full, cr[:, None], nty).min(0), 1)
+        hi = np.where(full.any(0), np.where(full, cr[:, None], -nty).max(0), 0)
+        outside = (cr[:, None] < lo[None, :]) | (cr[:, None] > hi[None, :])
+        rec[:, 3] = outside.reshape(-1)[order]
+        ranges.append(np.stack([lo, hi], axis=1).astype(np.int32))
         first = ptr[:-1][order][:, None] + np.arange(8)                     # a list's first 8 entries (0 beyond its end)
         rec[:, 4:12] = np.where(np.arange(8) < padded[order][:, None], ent[np.minimum(first, len(ent) - 1)], 0)
         recs.append(rec)
         ents.append(ent)
         wts.append(wt)
         base += len(ent)
-    return dict(wide_rec=np.stack(recs), wide_ent=np.concatenate(ents), wide_w=np.concatenate(wts))
+    return dict(wide_rec=np.stack(recs), wide_ent=np.concatenate(ents), wide_w=np.concatenate(wts),
+                wide_range=np.ascontiguousarray(np.stack(ranges)))
 
 
 def kb_plan(kappa, R, W=6):
@@ -157,7 +169,7 @@ def kb_plan(kappa, R, W=6):
     nu = (np.arange(R) - R / 2) / G
     phat = np.trapezoid(_kb(d, W, beta)[None, :] * np.cos(2 * math.pi * nu[:, None] * d[None, :]), d, axis=1)
     wide = _wide_lists(i0, w.astype(np.float32), G, W) if G % _WIDE_TW == 0 else \
-        dict(wide_rec=None, wide_ent=None, wide_w=None)
+        dict(wide_rec=None, wide_ent=None, wide_w=None, wide_range=None)
     return dict(**wide, **strips, R=R, G=G, W=W, J=J, traj_frames=Tt,
                 ix0=i0[..., 0].astype(np.int32), iy0=i0[..., 1].astype(np.int32),
                 wx=w[:, :, 0].astype(np.float32), wy=w[:, :, 1].astype(np.float32),
@@ -214,6 +226,7 @@ class RadialMRI(Operator):
         self.J = self._host["J"]
         self.max_chunk = max_chunk        # chains per pass: the oversampled grids are 8 G^2 bytes per frame
         self.grid_fft = 'auto'            # 'auto' | 'fused' (nufft_fft.hip) | 'library' (torch.fft around pad / crop)
+        self.adjoint = 'auto'             # 'auto' | 'full' (nufft_spread + nufft_inv_grid over the whole grid)
         self.fwd_interp = 'auto'          # 'auto' | 'fused' (column pass + interpolation in one kernel, no grid) | 'grid'
         self._dev = {}
 
@@ -313,8 +326,14 @@ class RadialMRI(Operator):
             vc = vals[i:i + self.max_chunk]
             n = vc.shape[0]
             grid = torch.empty(n, T, G, G, device=vals.device, dtype=torch.complex64)
-            _lib.check(L.nufft_spread(vc.data_ptr(), n * T, T, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
             cs = None if chain_scale is None else chain_scale[i:i + n].contiguous()
+            rng = self._host["wide_range"]
+            if self.adjoint == 'auto' and rng is not None and self._own_fft() and L.nufft_adjoint_supported(C.byref(plan), n):
+                work = torch.empty(n, T, R, G, device=vals.device, dtype=torch.complex64)
+                _lib.check(L.nufft_adjoint(vc.data_ptr(), n * T, T, C.byref(plan), rng.ctypes.data, _lib.ptr(cs), out_scale,
+                                           grid.data_ptr(), work.data_ptr(), out[i:i + n].data_ptr(), st), "nufft_adjoint")
+                continue
+            _lib.check(L.nufft_spread(vc.data_ptr(), n * T, T, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
             if self._own_fft():
                 work = torch.empty(n, T, R, G, device=vals.device, dtype=torch.complex64)
                 _lib.check(L.nufft_inv_grid(grid.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,

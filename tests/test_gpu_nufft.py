@@ -217,3 +217,44 @@ def test_fused_column_pass_and_interpolation_equals_the_grid_route(shared, dev):
     yb = ya + 0.1 * torch.randn(ya.shape, device=dev, generator=gen)             # a measurement per chain
     assert_close(a.loss(x, yb), b.loss(x, yb), 2e-6, "per-chain loss, per-chain measurement")
     assert torch.equal(a.gradient(x, y), ga)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_adjoint_that_skips_the_empty_tiles_equals_spread_plus_inverse(shared, dev):
+    """nufft_adjoint (the spread leaves the tiles outside the per-column row ranges unwritten, the inverse
+    column pass takes them as zero) against nufft_spread + nufft_inv_grid: bit for bit, with the scratch
+    grid pre-filled with NaN (nothing unwritten may be read)."""
+    import ctypes as C
+    from step_amd import _lib
+    from step_amd.forward_operator import golden_angle_radial
+    frames = 12
+    traj = golden_angle_radial(1 if shared else frames, 24, 192)
+    if shared:                                              # a trajectory that leaves whole tile columns empty
+        traj = traj[:, (np.abs(traj[0, :, 0]) < 60) & (np.abs(traj[0, :, 1]) < 90)]
+    op = make(spokes=24, frames=frames, trajectory=traj)
+    rec, rng = op._host["wide_rec"], op._host["wide_range"]
+    assert rec[:, :, 3].mean() > 0.15 and ((rec[:, :, 3] == 1) <= (rec[:, :, 2] == 0)).all()
+    if shared:
+        assert (rng[0, :, 0] > rng[0, :, 1]).any()          # empty columns: lo > hi
+    L, plan = _lib.lib(), op._plan(torch.device(dev))
+    gen = torch.Generator(device=dev).manual_seed(21)
+    for B in (16, 37):
+        assert L.nufft_adjoint_supported(C.byref(plan), B)
+        v = torch.randn(B, frames, op.J, 2, device=dev, generator=gen)
+        cs = torch.rand(B, device=dev, generator=gen) + 0.5
+        st = _lib.stream_of(v)
+        out_a, out_b = torch.empty(B, frames, 2, 192, 192, device=dev), torch.empty(B, frames, 2, 192, 192, device=dev)
+        work = torch.empty(B, frames, 192, 384, 2, device=dev)
+        grid = torch.full((B, frames, 384, 384, 2), float("nan"), device=dev)
+        _lib.check(L.nufft_adjoint(v.data_ptr(), B * frames, frames, C.byref(plan), rng.ctypes.data, cs.data_ptr(), 0.5,
+                                   grid.data_ptr(), work.data_ptr(), out_a.data_ptr(), st), "nufft_adjoint")
+        assert torch.isnan(grid).any()                      # something was skipped
+        _lib.check(L.nufft_spread(v.data_ptr(), B * frames, frames, C.byref(plan), grid.data_ptr(), st), "nufft_spread")
+        _lib.check(L.nufft_inv_grid(grid.data_ptr(), B * frames, frames, C.byref(plan), cs.data_ptr(), 0.5, work.data_ptr(),
+                                    out_b.data_ptr(), st), "nufft_inv_grid")
+        assert torch.isfinite(out_a).all() and torch.equal(out_a, out_b)
+    assert not L.nufft_adjoint_supported(C.byref(plan), 8)
+    a, b = op._type1(v, 1.0), None
+    op.adjoint = "full"
+    b = op._type1(v, 1.0)
+    assert torch.equal(a, b)
