@@ -329,7 +329,7 @@ int mri_loss_grad_mc(const float* x, const float* sens, int C, const float* y, i
  * ([nframes][C][2][R][R]), then mri_loss_grad on B x (T*C) frames (z as x, the multi-coil
  * measurement as y, per-frame mask tables repeated C times), then grad[f] = sum_c conj(S_c) * g[f][c].
  * Needs the two [nframes][C][2][R][R] buffers from the caller but runs on the pipelined kernels
- * (2.41 -> 1.85 ms at C = 8 and 64 chains; slower than mri_loss_grad_mc below 3 coils).
+ * (2.41 -> 1.74 ms at C = 8 and 64 chains; slower than mri_loss_grad_mc below 3 coils).
  * nframes <= 65535; 16-byte aligned buffers. */
 int mri_coil_mul(const float* x, const float* sens, int C, int nframes, int R, float* z, void* stream);
 int mri_coil_combine(const float* g, const float* sens, int C, int nframes, int R, float* out,
