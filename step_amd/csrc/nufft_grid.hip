@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
 #define NW_CHUNK 4           // entries whose values are requested together (= NW_PAD)
 #define NW_RP 16             // points per transposition round: 128-byte row segments (64-byte ones: 285 -> 389 us)
 #define NW_REC 16            // ints per tile record
+#ifndef NW_M
+#define NW_M 1               // tiles per wave (2: both tiles' first values in flight need 139 registers, 12 waves per CU: 0.33 ms against 0.28)
+#endif
 #define NW_LS (NW_RP + 1)
 #define NW_MIN_CHAINS 16
 __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restrict__ vals, NuPlan p, int T, int B,
@@ -380,60 +383,66 @@ __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restri
     const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * 64, tf = p.traj_frames == 1 ? 0 : t;
     const int nc = min(64, B - b0);
     const int G = p.G, ntx = G / NW_TW;
-    // the tile's record: id, first entry, entries, 0, then the sample ids of its first eight entries -- their
-    // values are requested after ONE trip to memory (record -> ids -> values would be two; under the
-    // kernel's own write stream every dependent trip costs microseconds)
-    const int32_t* __restrict__ rp = p.wide_rec + ((size_t)tf * p.wide_tiles + blockIdx.x) * NW_REC;
-    const int4 rec = *(const int4*)rp;
-    const int4 ja = *(const int4*)(rp + 4), jb = *(const int4*)(rp + 8);
-    if (skip_outside && rec.w) return;                        // nufft_adjoint: nobody reads the tiles outside the column ranges
+    // A tile's record: id, first entry, entries, outside, then the sample ids of its first eight entries -- their
+    // values are requested after ONE trip to memory.  NW_M > 1 lets a wave take NW_M consecutive records with
+    // all their first values requested at once; measured slower at 2 (139 registers), so a wave takes one tile.
+    const int32_t* __restrict__ rp = p.wide_rec + ((size_t)tf * p.wide_tiles + blockIdx.x * NW_M) * NW_REC;
     const int32_t* __restrict__ ent = p.wide_ent;
     const float* __restrict__ wts = p.wide_w;
     const float2* __restrict__ v = vals + ((size_t)(b0 + min(lane, nc - 1)) * T + t) * p.J;
-    float ar[NW_PTS], ai[NW_PTS];
+    int4 rec[NW_M];
+    float2 xa[NW_M][NW_CHUNK], xb[NW_M][NW_CHUNK];
 #pragma unroll
-    for (int k = 0; k < NW_PTS; ++k) ar[k] = ai[k] = 0.f;
-    auto add = [&](int e, const float2 (&x)[NW_CHUNK]) {
-#pragma unroll
-        for (int u = 0; u < NW_CHUNK; ++u) {
-            const float* __restrict__ w = wts + (size_t)(e + u) * NW_PTS;
-#pragma unroll
-            for (int k = 0; k < NW_PTS; ++k) {
-                ar[k] = fmaf(w[k], x[u].x, ar[k]);
-                ai[k] = fmaf(w[k], x[u].y, ai[k]);
-            }
-        }
-    };
-    {
-        const float2 xa[NW_CHUNK] = {v[ja.x], v[ja.y], v[ja.z], v[ja.w]};     // valid ids even where the list is shorter
-        const float2 xb[NW_CHUNK] = {v[jb.x], v[jb.y], v[jb.z], v[jb.w]};
-        if (rec.z > 0) add(rec.y, xa);
-        if (rec.z > NW_CHUNK) add(rec.y + NW_CHUNK, xb);
+    for (int m = 0; m < NW_M; ++m) {
+        rec[m] = *(const int4*)(rp + m * NW_REC);
+        const int4 ja = *(const int4*)(rp + m * NW_REC + 4), jb = *(const int4*)(rp + m * NW_REC + 8);
+        xa[m][0] = v[ja.x]; xa[m][1] = v[ja.y]; xa[m][2] = v[ja.z]; xa[m][3] = v[ja.w];   // valid ids even where the list is shorter
+        xb[m][0] = v[jb.x]; xb[m][1] = v[jb.y]; xb[m][2] = v[jb.z]; xb[m][3] = v[jb.w];
     }
-    for (int e = rec.y + 2 * NW_CHUNK; e < rec.y + rec.z; e += NW_CHUNK) {
-        float2 x[NW_CHUNK];
-#pragma unroll
-        for (int u = 0; u < NW_CHUNK; ++u) x[u] = v[ent[e + u]];
-        add(e, x);
-    }
-    const int ty = rec.x / ntx, tx = rec.x - ty * ntx;
     const int cl = lane / NW_RP, px = lane % NW_RP;           // store role: 64 / NW_RP chains x one row segment
 #pragma unroll
-    for (int r = 0; r < NW_PTS / NW_RP; ++r) {
+    for (int m = 0; m < NW_M; ++m) {
+        if (skip_outside && rec[m].w) continue;               // nufft_adjoint: nobody reads the tiles outside the column ranges
+        float ar[NW_PTS], ai[NW_PTS];
 #pragma unroll
-        for (int k = 0; k < NW_RP; ++k) s_tr[lane * NW_LS + k] = make_float2(ar[r * NW_RP + k], ai[r * NW_RP + k]);
-        __syncthreads();
-        float2* dst = grid + (((size_t)b0 * T + t) * G + ty * NW_TH + (r * NW_RP) / NW_TW) * G + tx * NW_TW + (r * NW_RP) % NW_TW + px;
+        for (int k = 0; k < NW_PTS; ++k) ar[k] = ai[k] = 0.f;
+        auto add = [&](int e, const float2 (&x)[NW_CHUNK]) {
 #pragma unroll
-        for (int i = 0; i < NW_RP; ++i) {
-            const int c = (64 / NW_RP) * i + cl;
-            if (c < nc) {
-                typedef float f2v __attribute__((ext_vector_type(2)));
-                const float2 o = s_tr[c * NW_LS + px];
-                __builtin_nontemporal_store(f2v{o.x, o.y}, (f2v*)(dst + (size_t)c * T * G * G));
+            for (int u = 0; u < NW_CHUNK; ++u) {
+                const float* __restrict__ w = wts + (size_t)(e + u) * NW_PTS;
+#pragma unroll
+                for (int k = 0; k < NW_PTS; ++k) {
+                    ar[k] = fmaf(w[k], x[u].x, ar[k]);
+                    ai[k] = fmaf(w[k], x[u].y, ai[k]);
+                }
             }
+        };
+        if (rec[m].z > 0) add(rec[m].y, xa[m]);
+        if (rec[m].z > NW_CHUNK) add(rec[m].y + NW_CHUNK, xb[m]);
+        for (int e = rec[m].y + 2 * NW_CHUNK; e < rec[m].y + rec[m].z; e += NW_CHUNK) {
+            float2 x[NW_CHUNK];
+#pragma unroll
+            for (int u = 0; u < NW_CHUNK; ++u) x[u] = v[ent[e + u]];
+            add(e, x);
         }
-        __syncthreads();
+        const int ty = rec[m].x / ntx, tx = rec[m].x - ty * ntx;
+#pragma unroll
+        for (int r = 0; r < NW_PTS / NW_RP; ++r) {
+#pragma unroll
+            for (int k = 0; k < NW_RP; ++k) s_tr[lane * NW_LS + k] = make_float2(ar[r * NW_RP + k], ai[r * NW_RP + k]);
+            __syncthreads();
+            float2* dst = grid + (((size_t)b0 * T + t) * G + ty * NW_TH + (r * NW_RP) / NW_TW) * G + tx * NW_TW + (r * NW_RP) % NW_TW + px;
+#pragma unroll
+            for (int i = 0; i < NW_RP; ++i) {
+                const int c = (64 / NW_RP) * i + cl;
+                if (c < nc) {
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    const float2 o = s_tr[c * NW_LS + px];
+                    __builtin_nontemporal_store(f2v{o.x, o.y}, (f2v*)(dst + (size_t)c * T * G * G));
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -569,8 +578,8 @@ int nufft_spread_impl(const float* vals_c64, int nframes, int T, const nufft_pla
     const int B = nframes / T;
     if (p.wide_tiles && B >= NW_MIN_CHAINS) {                   // a lane per chain
         const int ny = T * ((B + 63) / 64);
-        STEP_REQUIRE(p.G % NW_TW == 0 && ny <= 65535, "nufft_spread: G = %d, %d chains x %d frames", p.G, B, T);
-        hipLaunchKernelGGL(k_nufft_spread_wide, dim3(p.wide_tiles, ny), dim3(64), 0, (hipStream_t)stream,
+        STEP_REQUIRE(p.G % NW_TW == 0 && p.wide_tiles % NW_M == 0 && ny <= 65535, "nufft_spread: G = %d, %d chains x %d frames", p.G, B, T);
+        hipLaunchKernelGGL(k_nufft_spread_wide, dim3(p.wide_tiles / NW_M, ny), dim3(64), 0, (hipStream_t)stream,
                            (const float2*)vals_c64, p, T, B, skip_outside, (float2*)grid_c64);
         STEP_CHECK_LAUNCH("nufft_spread (wide)");
         return STEP_OK;
