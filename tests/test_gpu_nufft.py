@@ -149,6 +149,11 @@ def test_other_resolutions_take_the_library_transform(R, dev):
     g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
     assert_close(l_got, l_ref, RTOL, "loss")
     assert_close(g_got, g_ref, RTOL, "gradient")
+    # 16 chains take the lane-per-chain spread (any G with whole 16 x 2 tiles): the bits of the tile kernel
+    v = torch.randn(16, frames, op.J, 2, generator=gen).to(dev)
+    wide = op._type1(v, 1.0)
+    assert torch.equal(wide[3:4], op._type1(v[3:4], 1.0)) and torch.equal(wide[15:], op._type1(v[15:], 1.0))
+    assert not op._fused_fwd(dev)
     op.grid_fft = "fused"
     with pytest.raises(RuntimeError, match="built for R = 192"):
         op.gradient(x.to(dev), y.to(dev))
