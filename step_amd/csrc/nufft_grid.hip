@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
 // every lane and arrive in SCALAR registers, an entry costs one 8-byte load per lane and 64 v_fmac
 // with a scalar operand -- no test, no LDS, no divergence; each entry serves 64 chains, so the list
 // walk is paid once per 64 instead of once per 8.  The sums are transposed through LDS (one row of
-// 16 points at a time, stride 17: conflict-free both ways) so that the grid is still written as
+// 16 points at a time, XOR-swizzled: conflict-free both ways) so that the grid is still written as
 // 128-byte row segments.  Terms are added in list order (ascending j) with the same rounding
 // (fp32 product of the two weights, then fma): bit-identical to k_nufft_spread for finite input; a
 // zero weight times a non-finite value would reach points the footprint does not (the other kernel
@@ -374,11 +374,10 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
 #ifndef NW_M
 #define NW_M 1               // tiles per wave (2: both tiles' first values in flight need 139 registers, 12 waves per CU: 0.33 ms against 0.28)
 #endif
-#define NW_LS (NW_RP + 1)
 #define NW_MIN_CHAINS 16
 __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restrict__ vals, NuPlan p, int T, int B,
                                                           int skip_outside, float2* __restrict__ grid) {
-    __shared__ float2 s_tr[64 * NW_LS];
+    __shared__ float2 s_tr[64 * NW_RP];                       // 8 KB, XOR-swizzled instead of padded: 20 waves per CU, not 18
     const int lane = threadIdx.x;
     const int t = blockIdx.y % T, b0 = (blockIdx.y / T) * 64, tf = p.traj_frames == 1 ? 0 : t;
     const int nc = min(64, B - b0);
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restri
 #pragma unroll
         for (int r = 0; r < NW_PTS / NW_RP; ++r) {
 #pragma unroll
-            for (int k = 0; k < NW_RP; ++k) s_tr[lane * NW_LS + k] = make_float2(ar[r * NW_RP + k], ai[r * NW_RP + k]);
+            for (int k = 0; k < NW_RP; ++k) s_tr[lane * NW_RP + (k ^ ((lane >> 1) & 15))] = make_float2(ar[r * NW_RP + k], ai[r * NW_RP + k]);
             __syncthreads();
             float2* dst = grid + (((size_t)b0 * T + t) * G + ty * NW_TH + (r * NW_RP) / NW_TW) * G + tx * NW_TW + (r * NW_RP) % NW_TW + px;
 #pragma unroll
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restri
                 const int c = (64 / NW_RP) * i + cl;
                 if (c < nc) {
                     typedef float f2v __attribute__((ext_vector_type(2)));
-                    const float2 o = s_tr[c * NW_LS + px];
+                    const float2 o = s_tr[c * NW_RP + (px ^ ((c >> 1) & 15))];
                     __builtin_nontemporal_store(f2v{o.x, o.y}, (f2v*)(dst + (size_t)c * T * G * G));
                 }
             }
