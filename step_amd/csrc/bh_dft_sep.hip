@@ -41,13 +41,8 @@ __device__ __forceinline__ void fwd_strip(const float* __restrict__ xf, const fl
 #define SEP_LOAD(dst, blk)                                                         \
     _Pragma("unroll") for (int u = 0; u < SEP_U; ++u)                              \
         dst[u] = __builtin_nontemporal_load(xf + xo + (2 * ((blk) * SEP_U + u)) * W);
-#ifdef EXP_FWD_NOFLUSH
-#define SEP_FLUSH tot0 = acc0; tot1 = acc1;
-#define SEP_ACCINIT acc0 = tot0; acc1 = tot1;
-#else
 #define SEP_FLUSH _Pragma("unroll") for (int r = 0; r < 16; ++r) { tot0[r] += acc0[r]; tot1[r] += acc1[r]; }
 #define SEP_ACCINIT _Pragma("unroll") for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-#endif
 #define SEP_COMPUTE(src, blk)                                                      \
     {                                                                              \
         f32x16 acc0, acc1;                                                         \
@@ -141,11 +136,7 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
         const int xcol = wave * 32 + li;
         if (mine) fwd_strip(xf, eyl, h * W + xcol, W, nblk, h, li, scale, shift, clip_min, tot0, tot1);
         __syncthreads();                      // every wave is done reading the ey image
-#ifndef EXP_FWD_NOEPI
         if (mine) fwd_reduce(tot0, tot1, exr, exi, W, xcol, lane, lds + wave * 2048, sred + wave * 64);
-#else
-        if (mine) sred[wave * 64 + lane] = tot0[0] + tot1[0] + tot0[5] + tot1[9];
-#endif
     } else {
         float* scr = sred + nstrip * 64 + wave * 2048;
         for (int strip = wave; strip < nstrip; strip += SEP_WAVES) {
@@ -225,7 +216,6 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 8 : 2)) void k_dft_adj_sep(
     // k = 2F: gflux (ey = 1);  branch-free so that the table loads of all iterations overlap
     const float* eyr = ey_ri + ((size_t)t * 2 + 0) * 32 * H + y0;
     const float* eyi = ey_ri + ((size_t)t * 2 + 1) * 32 * H + y0;
-#ifndef EXP_ADJ_NOG
 #pragma unroll 4
     for (int e = threadIdx.x; e < KP * Hs; e += SEP_THREADS) {
         const int k = e / Hs, y = e - k * Hs;
@@ -237,7 +227,6 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 8 : 2)) void k_dft_adj_sep(
         if (k >= 2 * F) v = (k == 2 * F) ? g2[2 * F] : 0.f;
         G[e] = v;
     }
-#endif
     __syncthreads();
 
     const float* exr = ex_ri + ((size_t)t * 2 + 0) * 32 * W;
@@ -262,20 +251,13 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 8 : 2)) void k_dft_adj_sep(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#ifndef EXP_ADJ_NOMFMA
 #pragma unroll
             for (int s = 0; s < 32; ++s)
                 if (s < ksteps)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[(2 * s) * Hs], bx[s], acc, 0, 0, 0);
-#else
-            acc[0] = gp[0] * bx[0];
-#endif
             const int go = (tile * 32 + 4 * h) * W + xcol;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-#ifdef EXP_ADJ_NOSTORE
-                if (acc[r] == 1234567.f)
-#endif
                 gf[go + ((r & 3) + 8 * (r >> 2)) * W] = acc[r];
         }
     }

@@ -371,9 +371,7 @@ __global__ __launch_bounds__(256) void k_nufft_spread(const float2* __restrict__
 #define NW_CHUNK 4           // entries whose values are requested together (= NW_PAD)
 #define NW_RP 16             // points per transposition round: 128-byte row segments (64-byte ones: 285 -> 389 us)
 #define NW_REC 16            // ints per tile record
-#ifndef NW_M
 #define NW_M 1               // tiles per wave (2: both tiles' first values in flight need 139 registers, 12 waves per CU: 0.33 ms against 0.28)
-#endif
 #define NW_MIN_CHAINS 16
 __global__ __launch_bounds__(64) void k_nufft_spread_wide(const float2* __restrict__ vals, NuPlan p, int T, int B,
                                                           int skip_outside, float2* __restrict__ grid) {
