@@ -30,7 +30,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -56,10 +56,6 @@ def parse():
                    help="untimed steps before the warm-up until this much wall time has passed (clock ramp)")
     p.add_argument("--dry-run", action="store_true",
                    help="rank plumbing only (gloo, no GPU, no kernels): launch, barrier, MAX-reduce, JSON line")
-    p.add_argument("--barrier", default="gloo", choices=["gloo", "rccl"],
-                   help="what the barriers that bracket the timed region run on (N > 1): a host-side gloo group "
-                        "(default: no kernel lands on the GPU between the warm-up and the first timed step) or the "
-                        "RCCL process group")
     p.add_argument("--no-small-batches", action="store_true",
                    help="skip the extra B = 8 / B = 1 and sampler-loop measurements of the default blackhole run")
     return p.parse_args()
@@ -162,68 +158,22 @@ def cpu_baseline_mri(reps):
                 sample="%d x oracle gradient, B=8, 12x2x192x192, acc 6 / 24 ACS" % reps)
 
 
-def timed_region(step, steps, sync, barrier, reduce_max, gather):
-    """The contract's timed region, shared by the GPU run and --dry-run: barrier + sync, exactly
-    `steps` calls of `step`, sync, this rank's clock stops, barrier.  The rank's time is taken BEFORE
-    the closing barrier (a collective's own latency is not the workload's); the job's time is the
-    MAX over ranks, and every rank's own time is gathered for the JSON line."""
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    barrier()
-    return reduce_max(dt), gather(dt)
-
-
 def dry_run(a, rank, world):
     """The multi-rank plumbing of main() without a GPU (tests/test_bench_spawn.py): rendezvous over
-    gloo, the timed region of main() (barriers, per-rank clocks, MAX over ranks, gather), one JSON
-    line from rank 0.  A "step" sleeps 1 ms on rank 0, 2 ms on rank 1, ..."""
+    gloo, barrier, MAX over ranks of the per-rank time, one JSON line from rank 0."""
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")
-    comm = Comm(dist if world > 1 else None, None, torch.device("cpu"), world)
-    dt, per_rank = timed_region(lambda i: time.sleep(1e-3 * (1 + rank)), a.steps, lambda: None,
-                                comm.barrier, comm.reduce_max, comm.gather)
-    t = comm.reduce_max(1.0 + rank)
+        dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
         print(json.dumps(dict(metric="dry run", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                              max_over_ranks=t, ms_per_step=1e3 * dt / a.steps,
-                              per_rank_ms_per_step=[1e3 * v / a.steps for v in per_rank], dry_run=True)))
+                              max_over_ranks=t.item(), dry_run=True)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-class Comm:
-    """The only communication of the bench: bracket barriers, MAX and gather of one float per rank.
-    `dist` None = single process.  `side` = a host-side (gloo) group for the bracket barriers, or
-    None to run them on the default group (RCCL on GPUs)."""
-
-    def __init__(self, dist, side, dev, world):
-        self.dist, self.side, self.dev, self.world = dist, side, dev, world
-
-    def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier(group=self.side) if self.side is not None else self.dist.barrier()
-
-    def reduce_max(self, v):
-        if self.dist is None:
-            return float(v)
-        t = torch.tensor([v], device=self.dev, dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return t.item()
-
-    def gather(self, v):
-        if self.dist is None:
-            return [float(v)]
-        t = torch.tensor([v], device=self.dev, dtype=torch.float64)
-        out = [torch.zeros_like(t) for _ in range(self.world)]
-        self.dist.all_gather(out, t)
-        return [o.item() for o in out]
 
 
 def small_batch_line(op, y, dev, B, steps=2000):
@@ -293,12 +243,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.dry_run:
         return dry_run(a, rank, world)
-    dist = side = None
+    dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if a.barrier == "gloo":
-            side = dist.new_group(backend="gloo")
         if a.gpus != world and rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (a.gpus, world, world),
                   file=sys.stderr)
@@ -335,20 +283,15 @@ def main():
         x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
         y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
 
-    comm = Comm(dist, side, dev, world)
-
     def barrier():
         if dist is not None:
-            dist.barrier()                                       # RCCL
+            dist.barrier()
 
     # the first collectives of a process set RCCL up (communicator, kernels: hundreds of ms with the
     # GPU idle): here, ahead of the pre-warm, so that the barrier that opens the timed region takes
     # its 25 us and the clocks stay where the warm-up left them
     for _ in range(3):
         barrier()
-        comm.barrier()
-    # (the ranks leave that barrier together and the pre-warm below runs by wall time, so they reach
-    # the barrier that opens the timed region together too and nobody's GPU idles while waiting)
     # untimed, disclosed pre-warm: leave the clock ramp of an idle GPU before anything is timed
     t_pre = time.perf_counter()
     prewarm_steps = 0
@@ -361,19 +304,24 @@ def main():
     for _ in range(a.warmup):
         op.gradient(x, y, return_loss=True)
     torch.cuda.synchronize()
+    barrier()
     # HIP events (on the launch stream) bracket every kernel of every 4th step of the timed
     # region: each timed event pair costs a few microseconds of queue time, which on all steps
     # would add ~2 % to a 0.45 ms step
     prof = {}
-    last = {}
-
-    def step(i):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
         op._prof = prof if i % 4 == 0 else None
-        last["out"] = op.gradient(x, y, return_loss=True)
-
-    dt, per_rank = timed_region(step, a.steps, torch.cuda.synchronize, comm.barrier, comm.reduce_max, comm.gather)
+        grad, loss = op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
     op._prof = None
-    grad, loss = last["out"]
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
     assert torch.isfinite(loss).item()
 
     if rank == 0:
@@ -451,9 +399,6 @@ def main():
                    ms_per_step=1e3 * dt / a.steps, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=dtype, data="synthetic",
                    prewarm_ms=prewarm_ms, prewarm_steps=prewarm_steps,
-                   per_rank_ms_per_step=[1e3 * v / a.steps for v in per_rank],
-                   bracket_barrier=("none (one process)" if dist is None else
-                                    "gloo (host)" if side is not None else "rccl"),
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)

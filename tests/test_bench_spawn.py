@@ -23,8 +23,14 @@ def test_gpus_2_spawns_two_ranks():
     r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1
     assert r["max_over_ranks"] == 2.0            # rank 1's value: the MAX went over both ranks
+    # the timed region main() uses: every rank's own clock (stopped before the closing barrier) is
+    # in the line, the job's time is their MAX.  A dry-run step sleeps 1 ms on rank 0, 2 ms on rank 1
+    per = r["per_rank_ms_per_step"]
+    assert len(per) == 2 and r["ms_per_step"] == max(per)
+    assert 1.0 <= per[0] < 1.9 and 2.0 <= per[1] < 3.5
 
 
 def test_gpus_1_stays_in_process():
     r = _run(["--gpus", "1", "--dry-run"])
     assert r["n_gpus"] == 1 and r["max_over_ranks"] == 1.0
+    assert len(r["per_rank_ms_per_step"]) == 1 and r["ms_per_step"] == r["per_rank_ms_per_step"][0]
