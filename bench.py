@@ -248,6 +248,34 @@ def small_batch_line(op, y, dev, B, steps=2000):
                               algorithmic="whole step: 2 x 4*T*H*W bytes per chain x %d chains / ms_per_step" % B))
 
 
+def _split_ws_bytes(B, max_rows):
+    from step_amd import _lib
+    return _lib.lib().mri_loss_grad_split_ws_bytes(B, 12, max_rows, 0)
+
+
+def small_batch_line_mri(op, y, dev, B, steps=2000):
+    """ms per step and chain-steps/s of the MRI step at a small batch, with its HBM roofline on the
+    bytes that exist: x read and gradient written per chain, the shared measurement read once."""
+    g = torch.Generator(device=dev).manual_seed(1000 + B)
+    x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=g)
+    for _ in range(300):
+        op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        op.gradient(x, y, return_loss=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    byts = 16.0 * 12 * 192 * 192 * B + 8.0 * 12 * 192 * 192
+    gbs = byts / (ms * 1e-3) / 1e9
+    split = bool(y.shape[0] == 1 and op.kernel_variant == 0 and op.split_frames is not False
+                 and _split_ws_bytes(B, op._max_rows))
+    return dict(ms_per_step=ms, value=B / ms * 1e3, unit="chain-steps/s",
+                kernel="mri_loss_grad_split (a frame on 6 or 3 workgroups)" if split else "mri_loss_grad",
+                roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              algorithmic="(16*T*R*R x %d chains + 8*T*R*R) bytes / ms_per_step" % B))
+
+
 def sampler_lines(op, y, dev, B, steps=30, reps=3):
     """ms per step of the loops that call the operator -- MCMCSampler.sample and .optimize
     (sampler/daps.py:178-223) on pixel-space frames, hmc at momentum 0 (the shipped black-hole
@@ -439,13 +467,22 @@ def main():
                         algorithmic="(16 + 8*C)*T*R*R bytes per chain x %d chains, C = %d" % (B, a.coils),
                         kernels_ms=kern)
         else:
-            byts = 24.0 * 12 * 192 * 192 * B                  # read x, read y, write grad
-            gbs = byts / (kern["mri_loss_grad"] * 1e-3) / 1e9
+            # One measurement serves every chain (y_batch = 1, the sampler's case), so the bytes that
+            # exist are x read + gradient written per chain and y read once: 16*T*R*R*B + 8*T*R*R.
+            # That is the primary fraction; SURVEY 8d's 24*T*R*R per chain (a measurement per chain)
+            # over-counts y by B - 1 reads and is reported next to it.
+            exist = 16.0 * 12 * 192 * 192 * B + 8.0 * 12 * 192 * 192
+            survey = 24.0 * 12 * 192 * 192 * B
+            ms = kern["mri_loss_grad"]
+            gbs = exist / (ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=gbs / HBM_PEAK_GBS,
                         traffic=(measured_traffic("k_mri_loss_grad2p", B == 256)
                                  or measured_traffic("k_mri_loss_grad2", B == 256)),
-                        algorithmic="24*T*R*R bytes per chain x %d chains" % B, kernels_ms=kern)
+                        algorithmic="(16*T*R*R per chain + 8*T*R*R once: one measurement for all chains) x %d chains" % B,
+                        survey_8d_view=dict(achieved=survey / (ms * 1e-3) / 1e9, frac=survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            algorithmic="24*T*R*R bytes per chain x %d chains (a measurement per chain)" % B),
+                        kernels_ms=kern)
         out = dict(metric="DAPS Langevin steps/sec (fwd+adjoint)", value=world * B * a.steps / dt,
                    unit="chain-steps/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=1e3 * dt / a.steps, higher_is_better=True, scaling="weak",
@@ -473,6 +510,11 @@ def main():
             del x
             torch.cuda.empty_cache()
             out["sampler_loop"] = sampler_lines(op, y, dev, B)
+        if world == 1 and a.task == "mri" and a.coils == 0 and a.batch is None and not a.no_small_batches:
+            # the batches a GPU really sees: the reference runs B = 1 (sample.py:64-65) and config 5
+            # on 8 GPUs is 32 / 8 = 4 chains per GPU (frames shared between workgroups there)
+            del x
+            out["small_batches"] = {"B%d" % b: small_batch_line_mri(op, y, dev, b) for b in (4, 1)}
         if world == 1 and not a.no_cpu_baseline:
             if a.task == "blackhole":
                 out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)

@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -309,6 +309,27 @@ int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
                   const float* chain_scale, int variant, float* loss_part, float* loss,
                   float* loss_total, float* grad, void* stream);
+
+/* mri_loss_grad for batches that leave most of the chip idle (the reference samples one chain at a
+ * time, sample.py:64-65: 12 frames; BASELINE config 5 on 8 GPUs is 4 chains = 48 frames per GPU):
+ * 6 or 3 workgroups share a frame -- each takes column strips in the two column phases; the kept
+ * rows go from the forward column phase to the row phase through `ws` with a per-frame arrive /
+ * wait counter -- and the last workgroup adds the losses up (one launch, no finish kernel).  Same reference lines as mri_loss_grad
+ * (dynamic_mri.py:42-48, base.py:40-49); one measurement for all chains (y: [T][2][R][R]); masks of
+ * <= 64 kept rows per frame.  The gradient is bit-identical to mri_loss_grad's, the loss equal up to
+ * its summation order.
+ * mri_loss_grad_split_ws_bytes: size of `ws` for (B, T, max_rows, parts), or 0 when the split does not
+ * apply (the frames x 3 workgroups would not all be resident at once, i.e. more than 6 chains of 12
+ * frames on 256 CUs: use mri_loss_grad).
+ * ws: device memory, 16-byte aligned, ZEROED ONCE by the caller before its first use (its head is
+ * the counters); every call leaves it zeroed for the next one, whatever its shapes.  Calls that
+ * share a workspace must not overlap.  parts: 0 = 6 or 3, whichever fits; or 6, 3, 2 (2: measured no faster
+ * than the unsplit kernel). */
+size_t mri_loss_grad_split_ws_bytes(int B, int T, int max_rows, int parts);
+int mri_loss_grad_split(const float* x, const float* y, int B, int T, int R, const int32_t* rows,
+                        const int32_t* nrows, int mask_frames, int max_rows,
+                        const float* chain_scale, int parts, void* ws, size_t ws_bytes, float* loss,
+                        float* loss_total, float* grad, void* stream);
 
 /* Multi-coil variants -- NO REFERENCE COUNTERPART (the reference operator is single-coil,
  * dynamic_mri.py:42-48; BASELINE.json names the coil-sensitivity multiply): y_c = M * FFT2(fftshift(

@@ -5,6 +5,7 @@
 // SIGN = -1: forward transform  X[k] = sum_n x[n] exp(-2 pi i n k / N)   (torch.fft.fftn)
 // SIGN = +1: unnormalised inverse (the adjoint of the forward), exp(+2 pi i n k / N).
 #pragma once
+#include <math.h>
 
 #if defined(__HIPCC__)
 #define FFT_HD __host__ __device__ __forceinline__
@@ -21,10 +22,13 @@ FFT_HD cf32 c_add(cf32 a, cf32 b) { return c_make(a.x + b.x, a.y + b.y); }
 FFT_HD cf32 c_sub(cf32 a, cf32 b) { return c_make(a.x - b.x, a.y - b.y); }
 FFT_HD cf32 c_mul(cf32 a, cf32 b) { return c_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // multiply by exp(SIGN * i * theta) given (cos theta, sin theta)
+// Written with explicit fused multiply-adds: left to the compiler, which of the two products of
+// each component is fused into the add differs from call site to call site, and two kernels that
+// run the same transform on the same values would differ in the last bit.
 template <int SIGN>
 FFT_HD cf32 c_rot(cf32 a, float c, float s) {
-    return SIGN < 0 ? c_make(a.x * c + a.y * s, a.y * c - a.x * s)
-                    : c_make(a.x * c - a.y * s, a.y * c + a.x * s);
+    return SIGN < 0 ? c_make(fmaf(a.x, c, a.y * s), fmaf(a.y, c, -(a.x * s)))
+                    : c_make(fmaf(a.x, c, -(a.y * s)), fmaf(a.y, c, a.x * s));
 }
 // multiply by SIGN * i
 template <int SIGN>

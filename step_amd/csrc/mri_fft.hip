@@ -22,6 +22,7 @@
 #include "mri_lg2.h"
 #include "mri_lg4.h"
 #include "mri_lg2p.h"
+#include "mri_lg2s.h"
 
 #define MRI_R 192
 #define MRI_THREADS 512
@@ -427,6 +428,19 @@ __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2p(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Lg2DevCtx ctx{lds};
     lg2p_body(ctx, x, y, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part, unk_part, grad);
+}
+
+// ------------------------------------------- loss + gradient, several workgroups per frame (mri_lg2s.h)
+template <int SP>
+__global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2s(
+    const float* __restrict__ x, const float* __restrict__ y, const int* __restrict__ rows,
+    const int* __restrict__ nrows, int mask_frames, int T, int nframes, int nkc,
+    const float* __restrict__ chain_scale, float* part_out, float* unk_out, float* __restrict__ grad,
+    cf32* zs, unsigned* cnt, float* __restrict__ loss, float* __restrict__ total) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Lg2DevCtx ctx{lds};
+    lg2s_body<SP>(ctx, x, y, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, part_out, unk_out,
+                  grad, zs, cnt, loss, total);
 }
 
 // ------------------------------------------- loss + gradient, two workgroups per CU (mri_lg4.h)
@@ -864,4 +878,80 @@ extern "C" int mri_loss_grad(const float* x, const float* y, int y_batch, int B,
     return mri_loss_grad_impl("mri_loss_grad", x, y, y_batch, B, T, R, rows, nrows, mask_frames,
                               max_rows, chain_scale, variant, loss_part, loss, loss_total, grad,
                               (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------ small batches: a frame on several workgroups
+static int mri_cu_count() {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    return cus;
+}
+
+// workgroups per frame: 6 or 3, the most with which the whole grid (frames rounded up to a multiple of
+// 8, see lg2s_body) is resident at once; 0 = no split.  Two per frame are built and tested but not
+// chosen: measured 39.6 us per step at 8 chains against 38.6 us for the unsplit kernel (the exchange
+// costs what half a column phase saves).
+static int lg2s_parts(long long nframes, int want) {
+    const long long slots = mri_cu_count(), f8 = (nframes + 7) / 8 * 8;
+    const int cand[3] = {6, 3, 2};
+    for (int i = 0; i < 3; ++i)
+        if ((want == 0 ? cand[i] > 2 : want == cand[i]) && f8 * cand[i] <= slots) return cand[i];
+    return 0;
+}
+
+struct Lg2sWs { unsigned* cnt; float* part; float* unk; cf32* zs; size_t bytes; };
+static Lg2sWs lg2s_carve_ws(void* ws, long long nframes, int nkc) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    Lg2sWs w;
+    char* p = (char*)ws;
+    size_t o = 0;
+    w.cnt = (unsigned*)(p + o); o += up((size_t)(2 * nframes + 2) * 4);
+    w.part = (float*)(p + o);   o += up((size_t)nframes * 6 * 4);
+    w.unk = (float*)(p + o);    o += up((size_t)nframes * 6 * 4);
+    w.zs = (cf32*)(p + o);      o += (size_t)nframes * nkc * MRI_R * sizeof(cf32);
+    w.bytes = o;
+    return w;
+}
+
+extern "C" size_t mri_loss_grad_split_ws_bytes(int B, int T, int max_rows, int parts) {
+    if (B <= 0 || T <= 0 || max_rows > LG2_NKC_MAX) return 0;
+    const long long nframes = (long long)B * T;
+    if ((parts != 0 && parts != 2 && parts != 3 && parts != 6) || !lg2s_parts(nframes, parts)) return 0;
+    return lg2s_carve_ws(nullptr, nframes, pick_nkc(max_rows)).bytes;
+}
+
+extern "C" int mri_loss_grad_split(const float* x, const float* y, int B, int T, int R,
+                                   const int32_t* rows, const int32_t* nrows, int mask_frames,
+                                   int max_rows, const float* chain_scale, int parts, void* ws,
+                                   size_t ws_bytes, float* loss, float* loss_total, float* grad,
+                                   void* stream) {
+    const char* who = "mri_loss_grad_split";
+    STEP_REQUIRE(x && y && ws && loss, "%s: null pointer", who);
+    if (int rc = mri_check(who, B, T, R, rows, nrows, mask_frames)) return rc;
+    STEP_REQUIRE(max_rows <= LG2_NKC_MAX, "%s: masks of <= %d kept rows (got %d)", who, LG2_NKC_MAX, max_rows);
+    STEP_REQUIRE(parts == 0 || parts == 2 || parts == 3 || parts == 6, "%s: parts %d (0 auto, 2, 3, 6)", who, parts);
+    const long long nframes = (long long)B * T;
+    const int np = lg2s_parts(nframes, parts);
+    STEP_REQUIRE(np > 0, "%s: %lld frames x %d workgroups do not fit the %d CUs at once; use mri_loss_grad", who,
+                 nframes, parts ? parts : 2, mri_cu_count());
+    const int nkc = pick_nkc(max_rows);
+    const Lg2sWs w = lg2s_carve_ws(ws, nframes, nkc);
+    STEP_REQUIRE(ws_bytes >= w.bytes, "%s: workspace of %zu bytes, %zu needed", who, ws_bytes, w.bytes);
+    STEP_REQUIRE(((uintptr_t)ws & 15) == 0, "%s: workspace must be 16-byte aligned", who);
+    const size_t lds = lg2_lds_bytes(nkc);
+    const dim3 grid((unsigned)((nframes + 7) / 8 * 8 * np));
+    hipStream_t s = (hipStream_t)stream;
+#define LG2S_LAUNCH(SP)                                                                               \
+    step_allow_lds((const void*)k_mri_loss_grad2s<SP>, lds);                                          \
+    hipLaunchKernelGGL(k_mri_loss_grad2s<SP>, grid, dim3(LG2_THREADS), lds, s, x, y, rows, nrows,     \
+                       mask_frames, T, (int)nframes, nkc, chain_scale, w.part, w.unk, grad, w.zs,     \
+                       w.cnt, loss, loss_total)
+    if (np == 6) { LG2S_LAUNCH(1); }
+    else if (np == 3) { LG2S_LAUNCH(2); }
+    else { LG2S_LAUNCH(3); }
+#undef LG2S_LAUNCH
+    STEP_CHECK_LAUNCH(who);
+    return STEP_OK;
 }

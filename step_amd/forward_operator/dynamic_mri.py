@@ -86,6 +86,19 @@ class DynamicMRI(Operator):
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
     kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined, 3 two per CU, 4 persistent
+    # Batches whose frames leave most CUs idle (B * T * 3 <= CUs: up to 6 chains at T = 12) share a frame
+    # between 6 or 3 workgroups (mri_loss_grad_split; bit-identical gradient).  None = whenever it
+    # applies and kernel_variant is 0, False = never, 2 / 3 / 6 = that many workgroups per frame.
+    split_frames = None
+
+    def _split_ws(self, device, nbytes):
+        """The split kernel's workspace: zeroed once, left zeroed by every call (grown when needed)."""
+        key = ("split_ws", str(device))
+        ws = self._dev_tables.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(nbytes, device=device, dtype=torch.uint8)
+            self._dev_tables[key] = ws
+        return ws
 
     def _tables(self, device):
         key = str(device)
@@ -131,18 +144,30 @@ class DynamicMRI(Operator):
             raise ValueError("measurement shape %s does not match input %s"
                              % (tuple(y.shape), tuple(x.shape)))
         rows, nrows = self._tables(x.device)
-        part = torch.empty(2 * B * T, device=x.device, dtype=torch.float32)
         loss = torch.empty(B + 1, device=x.device, dtype=torch.float32)   # [B] per chain + their sum
         grad = torch.empty_like(x) if need_grad else None
+        ws_bytes = 0
+        if y.shape[0] == 1 and self.kernel_variant == 0 and self.split_frames is not False:
+            ws_bytes = _lib.lib().mri_loss_grad_split_ws_bytes(B, T, self._max_rows, int(self.split_frames or 0))
+        part = None if ws_bytes else torch.empty(2 * B * T, device=x.device, dtype=torch.float32)
         t0 = None
         if self._prof is not None:
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record(torch.cuda.current_stream(x.device))
-        rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
-                                      self.resolution, rows.data_ptr(), nrows.data_ptr(),
-                                      self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
-                                      self.kernel_variant, part.data_ptr(), loss.data_ptr(),
-                                      loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
+        if ws_bytes:
+            ws = self._split_ws(x.device, ws_bytes)
+            rc = _lib.lib().mri_loss_grad_split(x.data_ptr(), y.data_ptr(), B, T, self.resolution,
+                                                rows.data_ptr(), nrows.data_ptr(), self.mask.shape[1],
+                                                self._max_rows, _lib.ptr(chain_scale),
+                                                int(self.split_frames or 0), ws.data_ptr(), ws.numel(),
+                                                loss.data_ptr(), loss.data_ptr() + 4 * B, _lib.ptr(grad),
+                                                _lib.stream_of(x))
+        else:
+            rc = _lib.lib().mri_loss_grad(x.data_ptr(), y.data_ptr(), y.shape[0], B, T,
+                                          self.resolution, rows.data_ptr(), nrows.data_ptr(),
+                                          self.mask.shape[1], self._max_rows, _lib.ptr(chain_scale),
+                                          self.kernel_variant, part.data_ptr(), loss.data_ptr(),
+                                          loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
         if t0 is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record(torch.cuda.current_stream(x.device))

@@ -231,3 +231,59 @@ def test_persistent_kernel_is_bit_identical_to_the_pipelined_one(mode, acc, acs,
     assert torch.equal(res[4][0], res[2][0])
     assert torch.equal(res[4][2], res[2][2])
     assert torch.equal(res[4][1], res[2][1])
+
+
+@pytest.mark.parametrize("mode,acc,acs,B,parts", [
+    ("same_mask", 6, 24, 1, 6), ("same_mask", 6, 24, 1, 3), ("same_mask", 6, 24, 1, 2),
+    ("same_mask", 6, 24, 3, 6), ("same_mask", 6, 24, 4, 3), ("same_mask", 6, 24, 10, 2),
+    ("split_mask", 8, 12, 2, 6), ("random_split_mask", 6, 24, 5, 3), ("same_mask", 12, 0, 2, 6)])
+def test_split_frame_kernel_matches_the_unsplit_one(mode, acc, acs, B, parts, dev):
+    """mri_loss_grad_split (mri_lg2s.h: 6 / 3 / 2 workgroups share a frame at batches that leave the
+    chip idle) runs the transforms of the pipelined kernel on the same values in the same order:
+    the gradient is bit-identical, the loss equal to its summation order; also against the oracle,
+    with a chain scale, loss-only, and on two calls in a row through one workspace (the counters
+    at its head must come back to zero)."""
+    op = make_op(mode, acc_factor=acc, num_acs_lines=acs)
+    orc = MRIOracle(acc, mode, 192, 12, acs)
+    gen = torch.Generator().manual_seed(31 * acc + 7 * B + parts)
+    x = torch.randn(B, 12, 2, 192, 192, generator=gen)
+    y = orc(torch.randn(1, 12, 2, 192, 192, generator=gen)) + 0.1 * torch.randn(1, 12, 2, 192, 192, generator=gen)
+    xd, yd = x.to(dev), y.to(dev)
+    op.split_frames = False
+    g0, l0 = op.gradient(xd, yd, return_loss=True)
+    loss0 = op.loss(xd, yd)
+    op.split_frames = parts
+    for rep in range(2):
+        g1, l1 = op.gradient(xd, yd, return_loss=True)
+        assert torch.equal(g1, g0), "gradient bits (call %d)" % rep
+        assert_close(l1, l0, 1e-6, "loss sum")
+    loss1 = op.loss(xd, yd)                                   # loss only: no gradient, one wait
+    assert_close(loss1, loss0, 1e-6, "per-chain loss")
+    ws = op._dev_tables[("split_ws", str(xd.device))]
+    assert int(ws[:4 * (2 * B * 12 + 2)].view(torch.int32).abs().sum()) == 0, "counters / error word not zero"
+    g_ref, l_ref = orc.gradient(x, y.expand(B, -1, -1, -1, -1), return_loss=True)
+    assert_close(g1, g_ref, RTOL, "gradient vs the oracle")
+    assert_close(l1, l_ref, RTOL, "loss vs the oracle")
+    # auto: picks a split for this batch (or the unsplit kernel from 7 chains on), same bits
+    op.split_frames = None
+    g2, _ = op.gradient(xd, yd, return_loss=True)
+    assert torch.equal(g2, g0)
+    # through autograd with a per-chain upstream gradient
+    xr = xd.clone().requires_grad_(True)
+    wts = torch.linspace(0.5, 1.5, B, device=dev)
+    (op.loss(xr, yd) * wts).sum().backward()
+    assert_close(xr.grad, g0 * wts.view(-1, 1, 1, 1, 1), 1e-6, "weighted gradient")
+
+
+def test_split_frame_applies_to_small_batches_only(dev):
+    from step_amd import _lib
+    L = _lib.lib()
+    assert L.mri_loss_grad_split_ws_bytes(1, 12, 52, 0) > 0
+    assert L.mri_loss_grad_split_ws_bytes(6, 12, 52, 0) > 0
+    assert L.mri_loss_grad_split_ws_bytes(7, 12, 52, 0) == 0 and L.mri_loss_grad_split_ws_bytes(7, 12, 52, 2) > 0          # 88 frames x 3 > 256 CUs
+    assert L.mri_loss_grad_split_ws_bytes(4, 12, 108, 0) == 0          # more kept rows than the row buffer
+    op = make_op("same_mask")
+    x = torch.randn(12, 12, 2, 192, 192, device=dev)
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev))
+    op.gradient(x, y)                                               # 12 chains: the unsplit kernel
+    assert ("split_ws", str(x.device)) not in op._dev_tables

@@ -29,6 +29,10 @@ def test_single_coil_unit_sensitivity_is_the_single_coil_kernel(mode, split, dev
     mc, sc = make(mode, sens=sens), get_operator("mri", mode=mode, **CFG)
     mc.split_coils = split
     sc.kernel_variant = 0 if split else 1
+    # 3 chains leave the chip idle: the single-coil operator would share each frame between workgroups
+    # (mri_loss_grad_split: same gradient bits, the loss summed in another order); the multi-coil split
+    # path runs the unsplit kernel on its B x (T C) frames, so that is the one to compare bits with
+    sc.split_frames = False
     gen = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(3, 12, 2, 192, 192, device=dev, generator=gen)
     y = sc(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)) + 0.1 * torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)
