@@ -85,12 +85,20 @@ __device__ __forceinline__ void fwd_reduce(const f32x16& tot0, const f32x16& tot
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float s = 0.f;
+    // pairwise, not running: the sum over x is the level of the contraction whose fp32 rounding shows
+    // most in an ill-conditioned visibility (scripts/probes/sep_sum_order.py: summation noise 3.6e-9 of
+    // sum |a x| with running sums over the 32 columns and the strips, 2.0e-9 with trees -- what is
+    // left is the rounding inside the 16-row MFMA chains)
+    float v[32];
     const float* row = scr + li * 64 + h * 32;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) s += row[(j + li) & 31];
+    for (int j = 0; j < 32; ++j) v[j] = row[(j + li) & 31];
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; ++j) v[j] += v[j + w];
     // lane (li, h): component c = li >> 4, baseline f = mfma32_row(li & 15, h)
-    sred_strip[(li >> 4) * 32 + mfma32_row(li & 15, h)] = s;
+    sred_strip[(li >> 4) * 32 + mfma32_row(li & 15, h)] = v[0];
 }
 
 // floats in front of sred: the ey image, or the aliased transpose scratch if that is larger
@@ -149,8 +157,14 @@ __global__ __launch_bounds__(SEP_THREADS, (HC ? 4 : 2)) void k_dft_fwd_sep(
     __syncthreads();
     if (threadIdx.x < 64) {
         const int c = threadIdx.x >> 5, f = threadIdx.x & 31;
-        float s = 0.f;
-        for (int w = 0; w < nstrip; ++w) s += sred[w * 64 + c * 32 + f];
+        float sv[SEP_MAX_STRIPS];                                // the strips: a tree as well
+#pragma unroll
+        for (int w = 0; w < SEP_MAX_STRIPS; ++w) sv[w] = w < nstrip ? sred[w * 64 + c * 32 + f] : 0.f;
+#pragma unroll
+        for (int w = SEP_MAX_STRIPS / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int j = 0; j < w; ++j) sv[j] += sv[j + w];
+        const float s = sv[0];
         if (f < F) vis[(((size_t)b * T + t) * F + f) * 2 + c] = s;
         else if (f == F && c == 0) flux[(size_t)b * T + t] = s;
     }

@@ -301,13 +301,12 @@ def test_full_size_matches_golden(dft, golden, dev):
     grad, lsum = op.gradient(x.to(dev), y, return_loss=True)
     assert_close(lsum, g["x_loss_sum"], RTOL, "full loss")
     gc = grad.cpu()
-    # The gradient is dominated by v/|v|^2 of ONE nearly vanishing visibility (|v| = 0.74 where
-    # sum |a x| = 1.6e4: condition number 2e4, so fp32 rounding leaves ~1e-4 on it for any
-    # summation order).  Its rounding error is a one-sample draw for the reference (3.7e-5 here)
-    # and for us (1.5e-4): both are measured against the fp64 evaluation, with a slack of 6 on
-    # that single draw; the well-conditioned small fixtures hold the 1e-4 bar outright.
-    assert_as_accurate(gc.flatten()[::97], g["x_grad_sub"], g["x_grad64_sub"], RTOL, "full gradient",
-                       slack=6.0)
+    # This fixture's gradient max-norm is set by v/|v|^2 of ONE nearly vanishing visibility (|v| = 0.74
+    # where sum |a x| = 1.6e4: condition number 2e4), i.e. by a single draw of the fp32 summation noise
+    # -- 3.7e-5 for the reference, ~1e-4 for any fp32 order (scripts/probes/sep_sum_order.py).  Its
+    # pixel-wise check used to pass through a slack of 6 on that draw; it is retired instead: the
+    # pixel-wise 1e-4 bar at this size is asserted plainly on `bh_full_wc` (all three paths) and
+    # per path and seed against fp64 on `bh_full_seeds`.  What remains here needs no slack.
     assert_close(gc.flatten(2).sum(-1), g["x_grad_frame_sum"], RTOL, "per-frame gradient sums")
     assert abs(gc.abs().sum().item() - float(g["x_grad_abs_sum"])) <= RTOL * float(g["x_grad_abs_sum"])
 
@@ -358,8 +357,7 @@ def test_full_size_error_distribution_per_path(golden, dev, capsys):
     reference formulas, next to the reference's own fp32 error -- per path, no shared slack.
     Visibilities hold 1e-4 outright on every seed and path; the gradient's error, a draw of the
     rounding noise times a condition number of 1e4-1e5, is asserted per path: geometric mean over
-    the seeds <= 1e-4 for every path, every single seed <= 1e-4 for the default 3 x bf16 path and
-    the dense path (<= 2e-4 for the fp32-MFMA fallback `sep`, see the table below), and the
+    the seeds <= 1e-4 for every path, every single seed <= 1e-4 for every path, and the
     3 x bf16 path not systematically worse than the fp32-MFMA path."""
     g = golden("bh_full_seeds")
     seeds = [int(s) for s in g["seeds"]]
@@ -386,16 +384,17 @@ def test_full_size_error_distribution_per_path(golden, dev, capsys):
               + " ".join("%.1e" % float(g["s%d_cond_min_ratio" % s]) for s in seeds))
         for k in ("ref", "sep3", "sep", "dense"):
             print("  %-6s %s   geo-mean %.2e" % (k, " ".join("%.2e" % err[k, s] for s in seeds), gm(k)))
-    # measured (MI355X, round 2):   seed 101   102      103      104      geo-mean
+    # measured (MI355X, round 3):   seed 101   102      103      104      geo-mean
     #   reference fp32 (CPU)        3.3e-06  1.7e-06  1.3e-06  1.1e-05  3.0e-06
-    #   sep3  (3 x bf16, default)   6.0e-06  6.9e-06  4.2e-06  4.8e-05  9.6e-06
-    #   sep   (fp32 MFMA)           6.0e-06  1.2e-05  6.5e-06  1.2e-04  1.6e-05
+    #   sep3  (3 x bf16, default)   6.0e-06  6.9e-06  4.1e-06  4.8e-05  9.5e-06
+    #   sep   (fp32 MFMA)           1.8e-05  7.5e-06  1.1e-05  7.1e-05  1.8e-05
     #   dense (fp32 MFMA, split-K)  1.6e-05  1.5e-06  6.6e-06  3.8e-05  8.7e-06
-    # i.e. every path is at 1e-5 on the three seeds with min |v| / sum|a x| >= 1.2e-4, and the
-    # default path holds 1e-4 on every seed.  Seed 104 has one visibility at 3.2e-5 of sum|a x|
-    # (condition number 3e4): there the fp32-MFMA `sep` path, whose accumulation order differs
-    # from torch's pairwise sum, lands at 1.2e-4 -- its own, separately stated bound is 2e-4.
-    cap = {"sep3": RTOL, "dense": RTOL, "sep": 2e-4}
+    # Seed 104 has one visibility at 3.2e-5 of sum|a x| (condition number 3e4): its error is one draw
+    # of the summation noise.  Round 2's `sep` summed the 32 columns of a strip and the strips as
+    # running sums (noise 3.6e-9 of sum|a x| in scripts/probes/sep_sum_order.py, 1.2e-4 on this seed,
+    # cap 2e-4); with trees there (2.0e-9: what is left is the rounding inside the 16-row MFMA chains)
+    # it holds the common 1e-4 cap.
+    cap = {"sep3": RTOL, "dense": RTOL, "sep": RTOL}
     for k in ("sep3", "sep", "dense"):
         assert gm(k) <= RTOL, (k, gm(k))
         for s in seeds:
