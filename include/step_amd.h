@@ -211,7 +211,9 @@ int bh_closure_observe(const float* vis_c64, const float* sigma, int B, const bh
  *   - one measurement for all chains (y->batch == 1) and w_vis == w_amp == 0 (the shipped config). */
 
 /* frame_tab: HOST int32 [T][2][64][2]: for frame t, kind (0 triangles, 1 quadrangles), slot j:
- * (closure id k or -1, packed local baseline indices 5 bits each + conjugate flags from bit 15). */
+ * (closure id k or -1, packed local baseline indices 5 bits each + conjugate flags from bit 15).
+ * This builder runs on the host and writes host memory; bh_loss_grad_sep3 below reads the table
+ * from inside a kernel and needs a DEVICE copy of it (hipMemcpy the T*2*64*2 int32 once). */
 int bh_build_frame_closures(const int64_t* cp_index, const int64_t* cp_conj, int64_t n_tri,
                             const int64_t* camp_index, int64_t n_quad, int T, int F,
                             int32_t* frame_tab);
@@ -258,7 +260,10 @@ typedef struct {               /* the state update fused into the adjoint: no gr
     int32_t* nan_flag;
 } bh_update_t;
 
-/* loss [B], chi2 [B][5] (may be NULL), loss_total (may be NULL) = sum of loss[],
+/* frame_tab: DEVICE pointer to a copy of the host table bh_build_frame_closures fills (like every
+ * pointer of this call except the structs themselves, `w` and update->mcmc); a pageable host
+ * pointer is refused with STEP_E_INVALID instead of faulting in the kernel.
+ * loss [B], chi2 [B][5] (may be NULL), loss_total (may be NULL) = sum of loss[],
  * grad [B][T][H*W] = out_scale * chain_scale[b] * d loss[b] / d x' with x' = 0.5 x + 0.5
  * (out_scale = 0.5 gives d loss / d x; chain_scale may be NULL).
  * Exactly one of `grad` and `update` is non-NULL: with `update` the gradient is not written
@@ -498,10 +503,11 @@ int mcmc_update(float* x, float* velocity, const float* grad, const float* xt, c
  * W > 0 = the chain is rows of W elements and a call covers four consecutive rows of one column
  * (call (row / 4) * W + column, its k-th normal for row 4 (row / 4) + k) -- the layout the
  * black-hole adjoint draws in when it applies the update itself (bh_update_t), so that a chain
- * gets the same noise on both routes; costs four calls per four elements here.  W % 4 == 0,
- * chain_len % (4 W) == 0.
- * eps_out (may be NULL): receives the noise that was used.  chain_len % 4 == 0, 16-byte aligned
- * buffers. */
+ * gets the same noise on both routes; costs four calls per four elements here.  chain_len % W == 0.
+ * eps_out (may be NULL): receives the noise that was used.
+ * With 16-byte aligned buffers, chain_len % 4 == 0 (and W % 4 == 0, chain_len % (4 W) == 0 in the
+ * quad layout) the kernel moves float4s; otherwise it draws the same numbers one element at a time
+ * (element j of a chain: normal j & 3 of call j >> 2), so any chain length and any offset view works. */
 int mcmc_update_philox(float* x, float* velocity, const float* grad, const float* xt,
                        const float* prior, int64_t n, const mcmc_params_t* p, const int64_t* seeds,
                        int64_t chain_len, int64_t step, const int64_t* step_dev, int64_t quad_w,

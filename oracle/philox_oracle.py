@@ -52,6 +52,6 @@ def chain_noise_quad(seed, step, chain_len, width):
     """The same draw in the column-quad layout (mcmc_update_philox with quad_w = width, and the
     black-hole adjoint's in-kernel Langevin step): the chain is rows of `width` elements and
     generator call (row // 4) * width + column supplies rows 4 (row // 4) .. + 3 of that column."""
-    assert width % 4 == 0 and chain_len % (4 * width) == 0
+    assert chain_len % (4 * width) == 0
     calls = chain_noise(seed, step, chain_len).reshape(chain_len // (4 * width), width, 4)
     return np.ascontiguousarray(calls.transpose(0, 2, 1)).reshape(-1)

@@ -38,6 +38,7 @@
 #include "common.h"
 #include "closure_math.h"
 #include "mcmc_elem.h"
+#include <atomic>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -895,6 +896,25 @@ extern "C" int bh_dft_adj_sep3_update(const float* ey_ri, const float* ex_ri, in
     return STEP_OK;
 }
 
+// frame_tab is dereferenced by the forward kernel: the table that bh_build_frame_closures fills on the
+// HOST has to be handed over as a device copy (or pinned host memory).  A pageable host pointer
+// would be a GPU memory fault, so it is refused here; the last accepted pointer is remembered, the
+// lookup (no allocation, no synchronisation) runs once per table, not once per step.
+static bool s3_gpu_readable(const void* p) {
+    static std::atomic<const void*> accepted{nullptr};
+    if (accepted.load(std::memory_order_relaxed) == p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                             // pageable host memory: not an error of ours to keep
+        return false;
+    }
+    if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeHost && a.type != hipMemoryTypeManaged &&
+        a.type != hipMemoryTypeArray)
+        return false;                                        // hipMemoryTypeUnregistered
+    accepted.store(p, std::memory_order_relaxed);
+    return true;
+}
+
 // ------------------------------------------------------------------------------- fused step
 extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const float* ex_ri, int T, int F,
                                  int H, int W, const float* x, int B, const bh_tables_t* tab,
@@ -904,6 +924,8 @@ extern "C" int bh_loss_grad_sep3(const float* ey_t, const float* ey_ri, const fl
                                  const bh_update_t* update, void* stream) {
     STEP_REQUIRE(ey_t && ey_ri && ex_ri && x && tab && frame_tab && y && w && ws && loss,
                  "bh_loss_grad_sep3: null pointer");
+    STEP_REQUIRE(s3_gpu_readable(frame_tab),
+                 "bh_loss_grad_sep3: frame_tab must be a DEVICE copy of the table bh_build_frame_closures fills on the host");
     STEP_REQUIRE((grad != nullptr) != (update != nullptr), "bh_loss_grad_sep3: pass either grad or update");
     STEP_REQUIRE(!update || update->x_inout == x, "bh_loss_grad_sep3: update->x_inout must be x");
     S3Update up{};

@@ -18,7 +18,8 @@
 // (read and written) keep the cache.
 struct McmcNoise {               // PHILOX instantiation only
     const int64_t* seeds;        // [n / chain_len] device
-    int64_t chain_f4;            // float4 per chain
+    int64_t chain_f4;            // float4 per chain (VEC = 4)
+    int64_t chain_len;           // elements per chain
     int64_t step;                // used when step_dev is null
     const int64_t* step_dev;     // device counter (graph replay): the step is read from here
     float* eps_out;              // optional: the noise that was used (recording, tests)
@@ -98,9 +99,27 @@ __global__ __launch_bounds__(256) void k_mcmc_update(float* __restrict__ x, floa
             for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) body(i);
         }
     } else {
+        const uint64_t step = PHILOX ? (uint64_t)(nz.step_dev ? *nz.step_dev : nz.step) : 0;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            float v;
-            const float xn = mcmc_elem(x[i], grad[i], xt[i], prior ? prior[i] : 0.f, eps ? eps[i] : 0.f,
+            float v, e = (!PHILOX && eps) ? eps[i] : 0.f;
+            if (PHILOX) {
+                // the numbers of the float4 path, one element at a time (chains whose length is not a
+                // multiple of 4, or buffers that are not 16-byte aligned): element j of a chain is
+                // normal j & 3 of call j >> 2; in the quad layout normal row & 3 of the column's call
+                const int64_t b = i / nz.chain_len, j = i - b * nz.chain_len;
+                uint64_t call = (uint64_t)(j >> 2);
+                int k = (int)(j & 3);
+                if (nz.quad_w > 0) {
+                    const int64_t row = j / nz.quad_w, col = j - row * nz.quad_w;
+                    call = (uint64_t)((row >> 2) * nz.quad_w + col);
+                    k = (int)(row & 3);
+                }
+                float nn[4];
+                philox_normals4(call, step, (uint64_t)nz.seeds[b], nn);
+                e = k == 0 ? nn[0] : k == 1 ? nn[1] : k == 2 ? nn[2] : nn[3];
+                if (nz.eps_out) nz.eps_out[i] = e;
+            }
+            const float xn = mcmc_elem(x[i], grad[i], xt[i], prior ? prior[i] : 0.f, e,
                                        rd_vel ? vel[i] : 0.f, p, v);
             if (wr_vel) vel[i] = v;
             x[i] = xn;
@@ -127,19 +146,25 @@ extern "C" int mcmc_update_philox(float* x, float* velocity, const float* grad, 
     STEP_REQUIRE(x && grad && xt && p && seeds, "mcmc_update_philox: null pointer");
     STEP_REQUIRE(p->algo == 0 || p->algo == 1, "mcmc_update_philox: algo %d draws no noise", p->algo);
     STEP_REQUIRE(p->algo != 1 || velocity, "mcmc_update_philox: hmc needs a velocity buffer");
-    STEP_REQUIRE(n > 0 && chain_len > 0 && n % chain_len == 0 && chain_len % 4 == 0,
-                 "mcmc_update_philox: n = %lld must be whole chains of chain_len = %lld (a multiple of 4)",
+    STEP_REQUIRE(n > 0 && chain_len > 0 && n % chain_len == 0,
+                 "mcmc_update_philox: n = %lld must be whole chains of chain_len = %lld",
                  (long long)n, (long long)chain_len);
     STEP_REQUIRE(step >= 0, "mcmc_update_philox: negative step");
-    STEP_REQUIRE(quad_w >= 0 && (quad_w == 0 || (quad_w % 4 == 0 && chain_len % (4 * quad_w) == 0)),
-                 "mcmc_update_philox: quad_w = %lld needs quad_w %% 4 == 0 and chains of whole groups of 4 rows",
-                 (long long)quad_w);
+    STEP_REQUIRE(quad_w >= 0 && (quad_w == 0 || chain_len % quad_w == 0),
+                 "mcmc_update_philox: quad_w = %lld: chains must be whole rows of quad_w elements", (long long)quad_w);
     const uintptr_t al = (uintptr_t)x | (uintptr_t)velocity | (uintptr_t)grad | (uintptr_t)xt |
                          (uintptr_t)prior | (uintptr_t)eps_out;
-    STEP_REQUIRE(al % 16 == 0, "mcmc_update_philox: buffers must be 16-byte aligned");
-    McmcNoise nz{seeds, chain_len / 4, step, step_dev, eps_out, quad_w};
-    hipLaunchKernelGGL((k_mcmc_update<4, true>), dim3((unsigned)mcmc_blocks(n, true)), dim3(256), 0,
-                       (hipStream_t)stream, x, velocity, grad, xt, prior, nullptr, n, *p, nan_flag, nz);
+    // float4 path: aligned buffers, chains of whole float4s and (quad layout) whole groups of four
+    // rows of whole float4s; anything else takes the same numbers one element at a time
+    const bool vec = al % 16 == 0 && chain_len % 4 == 0 &&
+                     (quad_w == 0 || (quad_w % 4 == 0 && chain_len % (4 * quad_w) == 0));
+    McmcNoise nz{seeds, chain_len / 4, chain_len, step, step_dev, eps_out, quad_w};
+    if (vec)
+        hipLaunchKernelGGL((k_mcmc_update<4, true>), dim3((unsigned)mcmc_blocks(n, true)), dim3(256), 0,
+                           (hipStream_t)stream, x, velocity, grad, xt, prior, nullptr, n, *p, nan_flag, nz);
+    else
+        hipLaunchKernelGGL((k_mcmc_update<1, true>), dim3((unsigned)mcmc_blocks(n, false)), dim3(256), 0,
+                           (hipStream_t)stream, x, velocity, grad, xt, prior, nullptr, n, *p, nan_flag, nz);
     STEP_CHECK_LAUNCH("mcmc_update_philox");
     return STEP_OK;
 }

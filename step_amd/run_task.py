@@ -77,13 +77,36 @@ def load_task(task, config=None):
     return cfg
 
 
-def build_operator(cfg, device):
+def resolve_array(path, config=None):
+    """The array file of the black-hole operator: the configured path as given, else relative to the
+    config file's directory and to its parent's parent (the reference keeps `configs/task/EHT2017.txt`
+    relative to the repository root while the YAML sits in configs/task/), else -- with a warning -- the
+    8-station stand-in shipped here (the reference's EHT2017.txt is not redistributed).
+    -> (path used, True if it is the stand-in)"""
+    cands = [path] if path else []
+    if path and config and not os.path.isabs(path):
+        d = os.path.dirname(os.path.abspath(config))
+        cands += [os.path.join(d, path), os.path.join(d, os.path.basename(path)),
+                  os.path.join(os.path.dirname(os.path.dirname(d)), path)]
+    for c in cands:
+        if os.path.exists(c):
+            return c, False
+    fallback = os.path.join(_HERE, "data", "array_8.txt")
+    import warnings
+    warnings.warn("run_task: array file %r not found (tried %s); using the 8-station stand-in %s -- F and the "
+                  "closure sets follow THAT table" % (path, ", ".join(cands) or "-", fallback))
+    return fallback, True
+
+
+def build_operator(cfg, device, config=None):
     kw = dict(cfg["forward_operator"])
     name = kw.pop("name")
     if name == "blackhole":
-        if not os.path.exists(kw.get("array", "")):          # the reference's EHT2017.txt is not shipped
-            kw["array"] = os.path.join(_HERE, "data", "array_8.txt")
+        kw["array"], standin = resolve_array(kw.get("array", ""), config)
         kw["device"] = device
+        op = get_operator(name, **kw)
+        op.array_file, op.array_is_standin = kw["array"], standin
+        return op
     return get_operator(name, **kw)
 
 
@@ -136,7 +159,7 @@ def main(argv=None):
         sc["mcmc_sampler_config"]["prior_solver"] = a.prior_solver
     sc["mcmc_sampler_config"]["noise"] = a.noise
     sc["mcmc_sampler_config"]["nan_guard"] = "chain"         # unrelated chains share a batch here
-    op = build_operator(cfg, device)
+    op = build_operator(cfg, device, a.config)
     dw = cfg["diffusion_wrapper"]
     model = StandInPrior(dw["video_shape"], dw["latent_shape"]).to(device)
     skw = dict(sc)
@@ -145,6 +168,9 @@ def main(argv=None):
         print("task %s on %d rank(s): operator %s, prior = StandInPrior (random weights; the pretrained STeP prior "
               "is a remote download), videos = synthetic, %d sample(s) x %d video(s)"
               % (a.task, world, type(op).__name__, a.num_samples, a.num_videos))
+        if getattr(op, "array_file", None):
+            print("array file: %s%s" % (op.array_file, " (stand-in: the configured file was not found)"
+                                        if op.array_is_standin else ""))
     stats = []
     for idx in range(a.num_videos):
         video = synthetic_video(a.task, idx, dw["video_shape"]).unsqueeze(0).to(device)
@@ -170,6 +196,8 @@ def main(argv=None):
                 vals = torch.cat([evaluator(video, obs, samples[i:i + 1].to(device))[main].reshape(-1).float().cpu()
                                   for i in range(samples.shape[0])]).numpy()
             stats.append(dict(video=idx, seconds=dt, samples=a.num_samples,
+                              **({"array_file": op.array_file, "array_is_standin": op.array_is_standin}
+                                 if getattr(op, "array_file", None) else {}),
                               samples_per_hour=3600.0 * a.num_samples / dt,
                               finite=bool(torch.isfinite(samples).all()),
                               metric=main, metric_max=float(vals.max()), metric_min=float(vals.min()),

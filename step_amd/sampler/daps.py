@@ -239,13 +239,20 @@ class MCMCSampler(nn.Module):
             seeds = seeds.to(device=x.device, dtype=torch.int64).contiguous()
             step_fn = self._philox_step_fn(x, xt_k, x0hat, operator, measurement, params, seeds, nan_flag,
                                            record)
+        steps_left = self.num_steps
+        # graph replay is for an operator called directly on a pixel-space state: through a
+        # LatentWrapper a step is the decoder's forward and autograd backward, which is not a
+        # fixed sequence of this library's launches -- those run the eager loop
+        from ..forward_operator.latent_wrapper import LatentWrapper
         if (self.graph and philox and not record and self.prior_solver != 'exact'
-                and self.nan_check == 'deferred' and self.num_steps > 1):
-            self._graph_loop(x, step_fn)
-            if nan_flag.item():
-                return self._nan_result(x)
-            return x.detach()
-        for _ in range(self.num_steps):
+                and self.nan_check == 'deferred' and self.num_steps > 1
+                and not isinstance(operator, LatentWrapper)):
+            steps_left -= self._graph_loop(x, step_fn)
+            if steps_left == 0:
+                if nan_flag.item():
+                    return self._nan_result(x)
+                return x.detach()
+        for _ in range(steps_left):
             if philox:
                 prior = self.get_prior_score(x, x0hat, xt, model, sigma) if step_fn.needs_prior else None
                 epsilon, fitting_loss = step_fn(self.noise_step, None, prior)
@@ -309,7 +316,9 @@ class MCMCSampler(nn.Module):
         return step
 
     def _graph_loop(self, x, step_fn):
-        """num_steps steps in place on x: one eager, one captured, num_steps - 1 replays."""
+        """num_steps steps in place on x: one eager, one captured, num_steps - 1 replays.
+        Returns the number of steps taken: num_steps, or 1 when the capture failed (the eager step
+        has advanced x and the step counter by one; the caller finishes in the eager loop)."""
         dev = x.device
         step_dev = torch.full((1,), self.noise_step, dtype=torch.int64, device=dev)
         prior = self._kernel_tensor(self.prior_score, x) if step_fn.needs_prior else None
@@ -321,15 +330,24 @@ class MCMCSampler(nn.Module):
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
+        taken = 1
         with torch.cuda.stream(side):
             one_step()                                   # eager: also warms every allocation size
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                one_step()                               # recorded, not run
-            for _ in range(self.num_steps - 1):
-                graph.replay()
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    one_step()                           # recorded, not run
+            except Exception as e:                       # a step that cannot be captured
+                import warnings
+                warnings.warn("MCMCSampler(graph=True): capture failed (%s); finishing eagerly" % (e,))
+                graph = None
+            if graph is not None:
+                for _ in range(self.num_steps - 1):
+                    graph.replay()
+                taken = self.num_steps
         cur.wait_stream(side)
-        self.noise_step += self.num_steps
+        self.noise_step += taken
+        return taken
 
     def sample_MH(self, xt, model, x0hat, operator, measurement, sigma, ratio, record=False,
                   verbose=False):

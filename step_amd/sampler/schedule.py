@@ -16,6 +16,12 @@ class EDMScheduler:
         self.num_steps = num_steps + 1                      # include the initial step
         # sigma_max is used as given: LatentDAPS passes a float32 0-d tensor per annealing step
         # (daps.py:301), and the reference's grid is then float32 tensor arithmetic, not float64
+        # ... but PyYAML reads the reference configs' `sigma_min: 1e-2` as a STRING (no dot in the
+        # mantissa), so strings and plain Python numbers are made floats; tensors stay what they are
+        if isinstance(sigma_max, (str, int)):
+            sigma_max = float(sigma_max)
+        if isinstance(sigma_min, (str, int)):
+            sigma_min = float(sigma_min)
         self.sigma_max, self.sigma_min = sigma_max, sigma_min
         p = int(timestep.split('-')[1])
         self._fn = lambda r: (sigma_max ** (1 / p) + r * (sigma_min ** (1 / p) - sigma_max ** (1 / p))) ** p

@@ -54,6 +54,38 @@ def test_philox_kernel_matches_the_oracle(dev):
     assert flag.item() == 0
 
 
+def test_philox_kernel_takes_any_chain_length_and_offset_views(dev):
+    """chain_len % 4 != 0 or buffers off 16-byte alignment: the element-at-a-time path draws the
+    numbers of the float4 path (element j of a chain = normal j & 3 of call j >> 2), linear and
+    quad layout -- MCMCSampler(noise='philox') on latent shapes that are not multiples of 4."""
+    from step_amd import _lib
+    from oracle.philox_oracle import chain_noise_quad
+    p = _lib.mcmc_params_t(0.7, 0.3, 1e-2, 0.1, 0.1414, 0.0, 1.4142, 0)      # langevin
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    for L, W, off in ((1001, 0, 0), (4 * 250, 0, 1), (6 * 10, 10, 0), (8 * 12, 12, 3)):
+        B = 2
+        seeds = torch.tensor([5, 2 ** 33 + 1], dtype=torch.int64, device=dev)
+        buf = [torch.randn(B * L + 8, device=dev, generator=gen) for _ in range(4)]
+        x, g, xt, eps = (b[off:off + B * L] for b in buf)                     # offset views
+        x0 = x.clone()
+        rc = _lib.lib().mcmc_update_philox(x.data_ptr(), None, g.data_ptr(), xt.data_ptr(), None, B * L, C.byref(p),
+                                           seeds.data_ptr(), L, 11, None, W, eps.data_ptr(), flag.data_ptr(),
+                                           _lib.stream_of(x))
+        _lib.check(rc, "mcmc_update_philox")
+        Lp = (L + 3) // 4 * 4
+        if W == 0:
+            want = np.stack([chain_noise(int(sd), 11, Lp)[:L] for sd in seeds.tolist()])
+        else:
+            rows = (L // W + 3) // 4 * 4
+            want = np.stack([chain_noise_quad(int(sd), 11, rows * W, W)[:L] for sd in seeds.tolist()])
+        got = eps.view(B, L).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), (L, W, off)
+        f = lambda v: torch.tensor(v, dtype=torch.float32).item()
+        s = -g * f(0.7) + (xt - x0) * f(0.3)
+        assert (x - (x0 + f(1e-2) * s + f(0.1414) * eps)).abs().max().item() <= 1e-5
+
+
 DAPS = dict(ann=dict(name="edm", num_steps=4, sigma_max=10.0, sigma_min=0.1),
             dif=dict(name="edm", num_steps=3, sigma_min=0.01),
             mc=dict(num_steps=5, lr=2e-6, tau=0.05, lr_min_ratio=0.1, prior_solver="gaussian",

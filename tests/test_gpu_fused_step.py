@@ -91,6 +91,34 @@ def test_fallbacks(dev):
     assert rc == -1 and b"spans frames" in _lib.lib().step_last_error()
 
 
+def test_host_frame_table_is_refused_not_dereferenced(dev):
+    """bh_build_frame_closures fills a HOST table; the fused step reads it inside a kernel and needs a
+    device copy.  A C caller who hands over the host table gets STEP_E_INVALID, not a GPU fault."""
+    import ctypes as C
+    from step_amd import _lib
+    op = make(dev, 5, 64)
+    x = torch.rand(2, 64, 1, 64, 64, device=dev) * 2 - 1
+    y = op(torch.rand(1, 64, 1, 64, 64, device=dev) * 2 - 1)
+    host_tab = op._frame_tab.cpu().numpy().copy()             # pageable host memory
+    meas, keep = op._meas(y)
+    B, T, M = 2, op.T, op.T * op.F
+    buf = torch.zeros(4 * B * T + 2 * B * M + B * T + B * op.cphase_dim + B * op.logcamp_dim + 8 * B, device=dev)
+    o = [0, 4 * B * T, 4 * B * T + 2 * B * M, 4 * B * T + 2 * B * M + B * T]
+    o.append(o[3] + B * op.cphase_dim)
+    o.append(o[4] + B * op.logcamp_dim)
+    base = buf.data_ptr()
+    ws = _lib.bh_step_ws_t(base + 4 * o[1], base + 4 * o[2], base + 4 * o[3], base + 4 * o[4], base)
+    grad = torch.empty(B, T, 64 * 64, device=dev)
+    args = lambda tab: (op._ey_t.data_ptr(), op._ey_ri.data_ptr(), op._ex_ri.data_ptr(), T, op.F, 64, 64,
+                        x.data_ptr(), B, C.byref(op._tab), tab, C.byref(meas), C.byref(op._weights), C.byref(ws),
+                        None, 0.5, base + 4 * o[5], None, None, grad.data_ptr(), None, _lib.stream_of(x))
+    rc = _lib.lib().bh_loss_grad_sep3(*args(host_tab.ctypes.data))
+    assert rc == -1 and b"DEVICE copy" in _lib.lib().step_last_error()
+    rc = _lib.lib().bh_loss_grad_sep3(*args(op._frame_tab.data_ptr()))     # the device copy: runs
+    _lib.check(rc, "bh_loss_grad_sep3")
+    assert_close(grad.view_as(x), op.gradient(x, y), 1e-6, "raw call vs the operator")
+
+
 @pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 1), (8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 1), (7, 128, 33)])
 def test_descent_step_equals_gradient_then_update(n_sites, imsize, B, dev):
     """descent_step (the update of MCMCSampler.optimize, daps.py:210-223, applied inside the

@@ -1,5 +1,6 @@
 """CPU: host logic of the sampler layer (registries, learning-rate decay, schedules, recorder,
 kernel parameter packing) -- no kernel launches."""
+import os
 import warnings
 
 import numpy as np
@@ -172,3 +173,36 @@ def test_blackhole_observation_container_semantics():
     assert p.detach() is None and not p.cphase.requires_grad                # in place, like the reference
     q = BlackHoleObservation().from_dict({"flux": f[8], "amp": f[2], "sigma_amp": f[3]})
     assert q.flux is f[8] and q.amp is f[2] and q.vis is None
+
+
+def test_scheduler_takes_the_reference_yaml_as_pyyaml_reads_it():
+    """PyYAML reads the reference configs' `sigma_min: 1e-2` / `1e-5` as STRINGS; a caller that
+    splats yaml.safe_load(...)['sampler'][...] into get_diffusion_scheduler (sample.py:52) must get
+    the same grid as with floats, and tensor sigmas must stay tensors (float32 arithmetic)."""
+    import yaml
+    from step_amd.sampler.schedule import get_diffusion_scheduler
+    cfg = yaml.safe_load("annealing_scheduler_config:\n  name: edm\n  num_steps: 25\n  sigma_max: 100\n"
+                         "  sigma_min: 1e-2\n  timestep: poly-7\n")["annealing_scheduler_config"]
+    assert isinstance(cfg["sigma_min"], str) and isinstance(cfg["sigma_max"], int)
+    a = get_diffusion_scheduler(**cfg)
+    b = get_diffusion_scheduler(name="edm", num_steps=25, sigma_max=100.0, sigma_min=1e-2, timestep="poly-7")
+    assert torch.equal(a.sigma_steps, b.sigma_steps) and a.sigma_steps[-1] == 0
+    c = get_diffusion_scheduler(name="edm", num_steps=3, sigma_max=torch.tensor(2.0), sigma_min="1e-5")
+    assert torch.is_tensor(c.sigma_max) and c.sigma_steps.dtype == torch.float32
+
+
+def test_run_task_array_file_resolution(tmp_path):
+    import warnings
+    from step_amd.run_task import resolve_array
+    (tmp_path / "configs" / "task").mkdir(parents=True)
+    cfgf = tmp_path / "configs" / "task" / "blackhole.yaml"
+    cfgf.write_text("x: 1\n")
+    arr = tmp_path / "configs" / "task" / "EHT2017.txt"
+    arr.write_text("#\n")
+    # the reference's relative path, started from another directory: found next to the config
+    got, standin = resolve_array("configs/task/EHT2017.txt", str(cfgf))
+    assert os.path.samefile(got, arr) and not standin
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got, standin = resolve_array("configs/task/NOPE.txt", str(cfgf))
+    assert standin and got.endswith("array_8.txt") and any("stand-in" in str(m.message) for m in w)
