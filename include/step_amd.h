@@ -307,9 +307,9 @@ int mri_adjoint(const float* g, int B, int T, int R, const int32_t* rows, const 
  * 1 = first-generation kernel (any mask; cross-checks),
  * 2 = pipelined kernel, one workgroup per frame (STEP_E_INVALID if a mask frame keeps more than 64 rows),
  * 4 = its persistent form (a workgroup walks several frames and requests the next frame's first
- * strips under the current frame's row and inverse phases; y_batch = 1 only; bit-identical to 2),
- * 3 = in-register column transforms with two workgroups per CU (<= 52 kept rows per frame; same
- * results to rounding; measured slower than 2 so far and never chosen by 0). */
+ * strips under the current frame's row and inverse phases; y_batch = 1 only; bit-identical to 2).
+ * (3 was a kernel with in-register column transforms and two workgroups per CU; it measured slower
+ * at every batch and left the library in round 3 -- scripts/probes/mri_lg4.h keeps it.) */
 int mri_loss_grad(const float* x, const float* y, int y_batch, int B, int T, int R,
                   const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
                   const float* chain_scale, int variant, float* loss_part, float* loss,

@@ -20,7 +20,6 @@
 #include "common.h"
 #include "fft_small.h"
 #include "mri_lg2.h"
-#include "mri_lg4.h"
 #include "mri_lg2p.h"
 #include "mri_lg2s.h"
 
@@ -443,18 +442,6 @@ __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2s(
                   grad, zs, cnt, loss, total);
 }
 
-// ------------------------------------------- loss + gradient, two workgroups per CU (mri_lg4.h)
-template <bool YQ>
-__global__ __launch_bounds__(LG4_THREADS, 2) void k_mri_loss_grad4(
-    const float* __restrict__ x, const float* __restrict__ y, int y_batch,
-    const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T,
-    int nframes, int nkc, const float* __restrict__ chain_scale, float* __restrict__ loss_part,
-    float* __restrict__ unk_part, float* __restrict__ grad) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    lg4_body<YQ>(lds, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
-                 loss_part, unk_part, grad);
-}
-
 // ------------------------------------------------------------------------------- adjoint only
 // out = A^H g = ifftshift( R^2 * IFFT2( M * g ) ): the vector-Jacobian product of mri_forward.
 __global__ __launch_bounds__(MRI_THREADS) void k_mri_adjoint(
@@ -803,15 +790,14 @@ int mri_loss_grad_impl(const char* who, const float* x, const float* y, int y_ba
                               hipStream_t s) {
     STEP_REQUIRE(x && y && loss_part && loss, "%s: null pointer", who);
     STEP_REQUIRE(y_batch == 1 || y_batch == B, "%s: measurement batch %d vs B=%d", who, y_batch, B);
-    STEP_REQUIRE(variant >= 0 && variant <= 4,
-                 "%s: variant %d (0 auto, 1 first generation, 2 pipelined, 3 two workgroups per CU, 4 persistent)", who, variant);
+    STEP_REQUIRE(variant == 0 || variant == 1 || variant == 2 || variant == 4,
+                 "%s: variant %d (0 auto, 1 first generation, 2 pipelined, 4 persistent; 3, the two-per-CU kernel "
+                 "that measured slower, left the library in round 3: scripts/probes/mri_lg4.h)", who, variant);
     STEP_REQUIRE(variant != 4 || (max_rows <= LG2_NKC_MAX && y_batch == 1),
                  "%s: the persistent kernel takes a batch-1 measurement and masks of <= %d kept rows", who, LG2_NKC_MAX);
     if (int rc = mri_check(who, B, T, R, rows, nrows, mask_frames)) return rc;
     STEP_REQUIRE(variant != 2 || max_rows <= LG2_NKC_MAX,
                  "%s: the pipelined kernel takes masks of <= %d kept rows (got %d)", who, LG2_NKC_MAX, max_rows);
-    STEP_REQUIRE(variant != 3 || max_rows <= LG4_NKC_MAX,
-                 "%s: the two-per-CU kernel takes masks of <= %d kept rows (got %d)", who, LG4_NKC_MAX, max_rows);
     const int nkc = pick_nkc(max_rows);
     float* unk = loss_part + (size_t)B * T;              // second part of the workspace
     int n_unk = 0;
@@ -828,21 +814,6 @@ int mri_loss_grad_impl(const char* who, const float* x, const float* y, int y_ba
         step_allow_lds((const void*)k_mri_loss_grad2p, lds);
         hipLaunchKernelGGL(k_mri_loss_grad2p, dim3(nframes < cus ? nframes : cus), dim3(LG2_THREADS), lds, s, x, y,
                            rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part, unk, grad);
-    } else if (variant == 3) {
-        const size_t lds = lg4_lds_bytes(nkc);
-        const int nframes = B * T;
-        if (y_batch == 1) {
-            n_unk = (B < LG2_UNK_PARTS ? B : LG2_UNK_PARTS) * T;
-            step_allow_lds((const void*)k_mri_loss_grad4<false>, lds);
-            hipLaunchKernelGGL(k_mri_loss_grad4<false>, dim3(nframes), dim3(LG4_THREADS), lds, s, x, y,
-                               y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
-                               loss_part, unk, grad);
-        } else {
-            step_allow_lds((const void*)k_mri_loss_grad4<true>, lds);
-            hipLaunchKernelGGL(k_mri_loss_grad4<true>, dim3(nframes), dim3(LG4_THREADS), lds, s, x, y,
-                               y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
-                               loss_part, unk, grad);
-        }
     } else if (max_rows <= LG2_NKC_MAX && variant != 1) {
         // every mask frame fits one row buffer: pipelined kernel
         const size_t lds = lg2_lds_bytes(nkc);

@@ -85,7 +85,7 @@ class DynamicMRI(Operator):
         self._dev_tables = {}
 
     _prof = None      # bench.py sets this to {} to collect (start, end) event pairs
-    kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined, 3 two per CU, 4 persistent
+    kernel_variant = 0       # mri_loss_grad's `variant`: 0 auto, 1 first generation, 2 pipelined, 4 persistent
     # Batches whose frames leave most CUs idle (B * T * 3 <= CUs: up to 6 chains at T = 12) share a frame
     # between 6 or 3 workgroups (mri_loss_grad_split; bit-identical gradient).  None = whenever it
     # applies and kernel_variant is 0, False = never, 2 / 3 / 6 = that many workgroups per frame.

@@ -181,36 +181,6 @@ def test_bench_batch_256_against_the_oracle_on_a_subsample(y_per_chain, dev):
     assert torch.isfinite(grad).all()
 
 
-@pytest.mark.parametrize("mode,acc,acs,ybatch", [("same_mask", 6, 24, 1), ("same_mask", 6, 24, 3),
-                                                 ("split_mask", 8, 12, 1), ("random_split_mask", 6, 24, 3),
-                                                 ("split_mask", 6, 24, 1), ("same_mask", 12, 8, 1)])
-def test_two_per_cu_kernel_matches_pipelined_and_oracle(mode, acc, acs, ybatch, dev):
-    """variant 3 (mri_lg4.h: in-register column transforms, two workgroups per CU) against the
-    pipelined kernel (variant 2) and the oracle: measurement per chain and shared, with 17 chains
-    so that some chains carry a share of the masked-out rows and some do not."""
-    op = make_op(mode, acc_factor=acc, num_acs_lines=acs)
-    orc = MRIOracle(acc, mode, 192, 12, acs)
-    gen = torch.Generator().manual_seed(31 * acc + acs + ybatch)
-    B = 3 if ybatch > 1 else 17
-    x = torch.randn(B, 12, 2, 192, 192, generator=gen)
-    y = orc(torch.randn(ybatch, 12, 2, 192, 192, generator=gen)) \
-        + 0.1 * torch.randn(ybatch, 12, 2, 192, 192, generator=gen)
-    op.kernel_variant = 3
-    g3, l3 = op.gradient(x.to(dev), y.to(dev), return_loss=True)
-    loss3 = op.loss(x.to(dev), y.to(dev))
-    op.kernel_variant = 2
-    g2, l2 = op.gradient(x.to(dev), y.to(dev), return_loss=True)
-    loss2 = op.loss(x.to(dev), y.to(dev))
-    assert_close(g3, g2, 2e-5, "gradient vs the pipelined kernel")
-    assert_close(loss3, loss2, 2e-5, "per-chain loss vs the pipelined kernel")
-    assert_close(l3, l2, 2e-5, "loss sum vs the pipelined kernel")
-    nb = min(B, 3)
-    yb = y if ybatch > 1 else y.expand(nb, -1, -1, -1, -1)
-    g_ref, _ = orc.gradient(x[:nb], yb[:nb], return_loss=True)
-    assert_close(g3[:nb], g_ref, RTOL, "gradient vs the oracle")
-    assert_close(loss3[:nb], orc.loss(x[:nb], yb[:nb]), RTOL, "loss vs the oracle")
-
-
 @pytest.mark.parametrize("mode,acc,acs,B", [("same_mask", 6, 24, 17), ("same_mask", 6, 24, 50),
                                             ("split_mask", 8, 12, 45), ("random_split_mask", 6, 24, 70)])
 def test_persistent_kernel_is_bit_identical_to_the_pipelined_one(mode, acc, acs, B, dev):
