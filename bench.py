@@ -307,8 +307,9 @@ def sampler_lines(op, y, dev, B, steps=30, reps=3):
         out[name] = dict(ms_per_step=ms, value=B / ms * 1e3, unit="chain-steps/s")
         del res
     out["config"] = dict(chains=B, steps=steps, algo="hmc, momentum 0", prior_solver="gaussian",
-                         note="sample_philox: update and noise inside the adjoint (langevin_step); "
-                              "optimize: update inside the adjoint (descent_step)")
+                         note="sample_torch_noise: torch.randn_like per step (the reference's draw), handed to the "
+                              "adjoint, which applies the update (langevin_step(eps=...)); sample_philox: update and "
+                              "noise inside the adjoint (langevin_step); optimize: update inside the adjoint (descent_step)")
     return out
 
 

@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -258,6 +258,11 @@ typedef struct {               /* the state update fused into the adjoint: no gr
     int64_t step;
     const int64_t* step_dev;
     int32_t* nan_flag;
+    /* eps (may be NULL; mcmc != NULL only): DEVICE noise tensor laid out like x.  When given, the
+     * step uses it instead of drawing (seeds / step / step_dev unused): the reference's own draw,
+     * torch.randn_like at daps.py:192, replayed -- the result equals
+     * mcmc_update(x, NULL, g, xt = x0hat, prior = NULL, eps, ...).  Read once, never written. */
+    const float* eps;
 } bh_update_t;
 
 /* frame_tab: DEVICE pointer to a copy of the host table bh_build_frame_closures fills (like every

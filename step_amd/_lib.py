@@ -59,7 +59,7 @@ class mcmc_params_t(C.Structure):
 class bh_update_t(C.Structure):
     _fields_ = [("x_inout", c_p), ("x0hat", c_p), ("lr", c_f), ("inv_sigma2", c_f),
                 ("mcmc", C.POINTER(mcmc_params_t)), ("seeds", c_p), ("step", C.c_int64),
-                ("step_dev", c_p), ("nan_flag", c_p)]
+                ("step_dev", c_p), ("nan_flag", c_p), ("eps", c_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/step_amd.h declares

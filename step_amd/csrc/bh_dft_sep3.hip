@@ -175,6 +175,9 @@ struct S3FusedAdj {
 // MCMCSampler.optimize (daps.py:210-223), x -= lr (g + (x - x0hat) / sigma^2), is applied where
 // the tile would have been written: x and x0hat are read, x is written, and the gradient never
 // reaches HBM (one 1 GB write and one 1 GB read less per step at 64 chains).
+// UPD == 4 / 5: the same two steps with the noise READ from a tensor laid out like x (the reference's
+// own draw, torch.randn_like at daps.py:192, replayed): one extra stream instead of the update
+// kernel's six.
 // UPD == 2 / 3: the Langevin / momentum-free HMC step of MCMCSampler.sample (daps.py:135-144,
 // :93-104 with the score terms that depend on x collapsed into (x0 - x) / sigma^2: what the
 // 'gaussian' prior solver's (xt - x) / sigma^2 + (x0hat - xt) / sigma^2 adds up to) in the same
@@ -186,7 +189,8 @@ struct S3Update {
     const float* x0;          // x0hat
     float lr, inv_sigma2;
     mcmc_params_t p;          // UPD >= 2
-    const int64_t* seeds;     // [B] device
+    const float* eps;         // UPD >= 4: the noise, laid out like x (torch's draw, read once) -- no generator
+    const int64_t* seeds;     // UPD 2 / 3: [B] device
     int64_t step;
     const int64_t* step_dev;  // device step counter (graph replay) or null
     int32_t* nan_flag;        // or null
@@ -492,7 +496,9 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
         if (threadIdx.x == 0) *sum_out = sacc;
     }
     const int nkb = (F + 1 + 15) >> 4;                       // 1 or 2 blocks of 16 baselines
-    const uint64_t nstep = UPD >= 2 ? (uint64_t)(up.step_dev ? *up.step_dev : up.step) : 0;
+    constexpr bool EPSMEM = UPD >= 4;                        // noise from memory instead of Philox
+    constexpr int UALGO = UPD >= 2 ? ((UPD - 2) & 1) : 0;    // 0 langevin, 1 hmc at momentum 0
+    const uint64_t nstep = (UPD >= 2 && !EPSMEM) ? (uint64_t)(up.step_dev ? *up.step_dev : up.step) : 0;
     bool bad = false;
     u32x4* eyp = lds4;
     float* gl = (float*)(lds4 + 24 * HH);                    // [S3_GCH chains][S3_GROW]
@@ -668,9 +674,10 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                 split3(wi, ih[kb], im[kb], il[kb]);
             }
             const size_t fo = ((size_t)b * T + t) * H * W + xcol;
-            const uint64_t seed = UPD >= 2 ? (uint64_t)up.seeds[b] : 0;
+            const uint64_t seed = (UPD >= 2 && !EPSMEM) ? (uint64_t)up.seeds[b] : 0;
             float* gf = (UPD ? up.x : grad) + fo;
             const float* x0f = UPD ? up.x0 + fo : nullptr;
+            const float* epf = EPSMEM ? up.eps + fo : nullptr;
 #pragma unroll 1
             for (int tile = tpart; tile < NTILE; tile += tsplit) {
 
@@ -709,6 +716,13 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
                             const int yy = ytop + (i & 3) + 8 * ((r0 + i) >> 2);
                             xh[i] = x0f[(mir ? H - 1 - yy : yy) * W];
                         }
+                        if (EPSMEM) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int yy = ytop + (i & 3) + 8 * ((r0 + i) >> 2);
+                                nz[i] = __builtin_nontemporal_load(epf + (mir ? H - 1 - yy : yy) * W);
+                            }
+                        } else {
 #pragma unroll
                         for (int jq = 0; jq < 2; ++jq) {
                             const int yq = ytop + 8 * ((r0 >> 2) + jq);          // first row of the quad, upper half
@@ -718,13 +732,14 @@ __global__ __launch_bounds__(S3_THREADS, 1) void k_dft_adj_s3(
 #pragma unroll
                             for (int k = 0; k < 4; ++k) nz[4 * jq + k] = n4[mir ? 3 - k : k];
                         }
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const int r = r0 + i;
                             const int yy = ytop + (r & 3) + 8 * (r >> 2);
                             const float g_ = mir ? ev[r] - od[r] : ev[r] + od[r];
                             float vdummy;
-                            const float xn = mcmc_elem_a<UPD - 2>(xo[i], g_, xh[i], 0.f, nz[i], 0.f, up.p, vdummy);
+                            const float xn = mcmc_elem_a<UALGO>(xo[i], g_, xh[i], 0.f, nz[i], 0.f, up.p, vdummy);
                             bad |= (xn != xn);
                             S3_STG(gf + (mir ? H - 1 - yy : yy) * W, xn);
                         }
@@ -822,15 +837,27 @@ static void launch_adj_s3(const float* ey_ri, const float* ex_ri, int T, int F, 
     hipLaunchKernelGGL((k_dft_adj_s3<H, W, FU, UP>), dim3(gx * T, tsplit), dim3(S3_THREADS), lds, st, ey_ri, ex_ri, \
                        gvis, gflux, chain_scale, grad, T, F, B, cpw, out_scale, sum_in, sum_n, sum_out,    \
                        fz ? *fz : S3FusedAdj{}, up ? *up : S3Update{})
-    const int mode = up ? (up->seeds ? 2 + up->p.algo : 1) : 0;     // 2: langevin, 3: hmc (momentum 0)
-    if (fz && mode == 3) { S3_ADJ_LAUNCH(true, 3); }
-    else if (mode == 3) { S3_ADJ_LAUNCH(false, 3); }
-    else if (fz && mode == 2) { S3_ADJ_LAUNCH(true, 2); }
-    else if (fz && mode == 1) { S3_ADJ_LAUNCH(true, 1); }
-    else if (fz) { S3_ADJ_LAUNCH(true, 0); }
-    else if (mode == 2) { S3_ADJ_LAUNCH(false, 2); }
-    else if (mode == 1) { S3_ADJ_LAUNCH(false, 1); }
-    else { S3_ADJ_LAUNCH(false, 0); }
+    // 0 gradient, 1 optimize, 2 / 3 langevin / hmc (momentum 0) with Philox noise, 4 / 5 the same with the noise read
+    const int mode = up ? (up->eps ? 4 + up->p.algo : up->seeds ? 2 + up->p.algo : 1) : 0;
+    if (fz) {
+        switch (mode) {
+            case 0: S3_ADJ_LAUNCH(true, 0); break;
+            case 1: S3_ADJ_LAUNCH(true, 1); break;
+            case 2: S3_ADJ_LAUNCH(true, 2); break;
+            case 3: S3_ADJ_LAUNCH(true, 3); break;
+            case 4: S3_ADJ_LAUNCH(true, 4); break;
+            default: S3_ADJ_LAUNCH(true, 5); break;
+        }
+    } else {
+        switch (mode) {
+            case 0: S3_ADJ_LAUNCH(false, 0); break;
+            case 1: S3_ADJ_LAUNCH(false, 1); break;
+            case 2: S3_ADJ_LAUNCH(false, 2); break;
+            case 3: S3_ADJ_LAUNCH(false, 3); break;
+            case 4: S3_ADJ_LAUNCH(false, 4); break;
+            default: S3_ADJ_LAUNCH(false, 5); break;
+        }
+    }
 #undef S3_ADJ_LAUNCH
 }
 
@@ -868,9 +895,9 @@ static int s3_make_update(const bh_update_t* u, S3Update* out, const char* who) 
     STEP_REQUIRE(p.algo == 0 || (p.algo == 1 && p.momentum == 0.f),
                  "%s: the in-adjoint step is langevin or hmc with momentum 0 (algo %d, momentum %g)", who,
                  p.algo, (double)p.momentum);
-    STEP_REQUIRE(u->seeds, "%s: the in-adjoint Langevin step draws its noise from per-chain seeds", who);
+    STEP_REQUIRE(u->seeds || u->eps, "%s: the in-adjoint Langevin step takes its noise from per-chain seeds or from `eps`", who);
     STEP_REQUIRE(u->step >= 0, "%s: negative step", who);
-    out->p = p; out->seeds = u->seeds; out->step = u->step; out->step_dev = u->step_dev;
+    out->p = p; out->eps = u->eps; out->seeds = u->eps ? nullptr : u->seeds; out->step = u->step; out->step_dev = u->step_dev;
     out->nan_flag = u->nan_flag;
     return STEP_OK;
 }

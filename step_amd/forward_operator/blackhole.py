@@ -931,16 +931,26 @@ class BlackHoleImagingTorch(Operator):
         return self.has_langevin_step and batch * self.T >= 256
 
     def langevin_step(self, x, y, x0hat, params, seeds, step=0, step_dev=None, nan_flag=None,
-                      return_loss=False):
+                      return_loss=False, eps=None):
         """One step of MCMCSampler.sample (daps.py:184-200) in place on x for the 'gaussian' prior
         solver, whose score terms add up to ``-g / tau^2 + (x0hat - x) / sigma^2``: langevin
         (params.algo 0) or hmc with momentum 0 (algo 1), the update applied by the adjoint kernel
         where it would have stored the gradient and the noise drawn there (Philox keyed by the
         chain's seed, column-quad layout) -- neither gradient nor noise reaches HBM.  Equals
         ``gradient`` + ``mcmc_update_philox(x, None, g, xt=x0hat, prior=None, ..., quad_w=W)``.
+        With ``eps`` (a noise tensor shaped like x, e.g. the reference's ``torch.randn_like``) nothing
+        is drawn: the adjoint reads it, ``seeds`` / ``step`` are unused, and the result equals
+        ``gradient`` + ``mcmc_update(x, None, g, xt=x0hat, prior=None, eps, ...)``.
         params: _lib.mcmc_params_t; seeds: int64 [B] on the device; step_dev: optional device
         int64 read instead of ``step`` (graph replay); nan_flag: optional device int32."""
         x0 = self._state_and_anchor(x, x0hat, "langevin_step")
+        if eps is not None:
+            # the noise as a tensor (torch's draw, daps.py:192): read by the adjoint, nothing is generated
+            if eps.dtype != torch.float32 or eps.shape != x.shape or eps.device != x.device or not eps.is_contiguous():
+                raise ValueError("langevin_step: eps must be contiguous float32 %s on %s" % (tuple(x.shape), x.device))
+            upd = _lib.bh_update_t(x.data_ptr(), x0.data_ptr(), 0.0, 0.0, C.pointer(params), None, 0, None,
+                                   _lib.ptr(nan_flag), eps.data_ptr())
+            return self._step_with_update(x, y, upd, return_loss)
         if seeds.dtype != torch.int64 or seeds.numel() != x.shape[0] or seeds.device != x.device or not seeds.is_contiguous():
             raise ValueError("langevin_step: seeds must be contiguous int64 [%d] on %s" % (x.shape[0], x.device))
         upd = _lib.bh_update_t(x.data_ptr(), x0.data_ptr(), 0.0, 0.0, C.pointer(params), seeds.data_ptr(),

@@ -239,6 +239,14 @@ class MCMCSampler(nn.Module):
             seeds = seeds.to(device=x.device, dtype=torch.int64).contiguous()
             step_fn = self._philox_step_fn(x, xt_k, x0hat, operator, measurement, params, seeds, nan_flag,
                                            record)
+        # torch noise, 'gaussian' solver, no carried velocity, an operator that applies the update in
+        # its adjoint: the step of the loop below in the operator's two or three launches, with the
+        # reference's own draw handed to the adjoint as a tensor (gradient and score never reach
+        # HBM; the 'gaussian' score's two xt terms are evaluated as their sum (x0hat - x) / sigma^2)
+        eps_adjoint = (not philox and self.fuse_langevin and self.prior_solver == 'gaussian'
+                       and (self.mc_algo == 'langevin' or self.momentum == 0)
+                       and getattr(operator, 'has_langevin_step', False))
+        x0_k = self._kernel_tensor(x0hat.detach(), x) if eps_adjoint else None
         steps_left = self.num_steps
         # graph replay is for an operator called directly on a pixel-space state: through a
         # LatentWrapper a step is the decoder's forward and autograd backward, which is not a
@@ -257,6 +265,10 @@ class MCMCSampler(nn.Module):
                 prior = self.get_prior_score(x, x0hat, xt, model, sigma) if step_fn.needs_prior else None
                 epsilon, fitting_loss = step_fn(self.noise_step, None, prior)
                 self.noise_step += 1
+            elif eps_adjoint:
+                epsilon = chain_randn_like(x, self.chain_generators)
+                fitting_loss = operator.langevin_step(x, measurement, x0_k, params, None, eps=epsilon,
+                                                      nan_flag=nan_flag, return_loss=record)
             else:
                 grad, fitting_loss = operator.gradient(x, measurement, return_loss=True)
                 prior = self.get_prior_score(x, x0hat, xt, model, sigma)

@@ -281,3 +281,61 @@ def test_sample_with_the_update_in_the_adjoint(algo, dev):
     assert not torch.equal(a, b)
     da, db = (a - x0).flatten(1), (b - x0).flatten(1)
     assert_close(da.std(dim=1), db.std(dim=1), 2e-2, "step size of the two routes")
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("n_sites,imsize,B", [(8, 256, 1), (8, 256, 3), (8, 256, 40), (5, 64, 2), (7, 128, 33)])
+def test_langevin_step_with_a_noise_tensor_equals_gradient_then_update(n_sites, imsize, B, algo, dev):
+    """langevin_step(eps=...): the step of MCMCSampler.sample with the reference's own draw
+    (torch.randn_like, daps.py:192) handed to the adjoint as a tensor == gradient() followed by
+    mcmc_update with xt = x0hat and no prior tensor, on the two-launch and the three-kernel path."""
+    import ctypes as C
+    from step_amd import _lib
+    op = make(dev, n_sites, imsize)
+    gen = torch.Generator(device=dev).manual_seed(300 + B)
+    x = torch.rand(B, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1
+    x0 = x + 0.05 * torch.randn(x.shape, device=dev, generator=gen)
+    eps = torch.randn(x.shape, device=dev, generator=gen)
+    y = op(torch.rand(1, 64, 1, imsize, imsize, device=dev, generator=gen) * 2 - 1)
+    g, total = op.gradient(x, y, return_loss=True)
+    lr = 1e-4
+    p = _lib.mcmc_params_t(30.0 / float(g.abs().max()), 40.0, lr, np.sqrt(lr), np.sqrt(2 * lr), 0.0, np.sqrt(2.0), algo)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    want = x.clone()
+    vel = torch.zeros_like(x) if algo == 1 else None
+    rc = _lib.lib().mcmc_update(want.data_ptr(), _lib.ptr(vel), g.data_ptr(), x0.data_ptr(), None, eps.data_ptr(),
+                                x.numel(), C.byref(p), flag.data_ptr(), _lib.stream_of(x))
+    _lib.check(rc, "mcmc_update")
+    got, eps_before = x.clone(), eps.clone()
+    got_total = op.langevin_step(got, y, x0, p, None, eps=eps, nan_flag=flag, return_loss=True)
+    assert_close(got_total, total, 1e-6, "loss at the old x")
+    assert flag.item() == 0 and torch.equal(eps, eps_before)
+    assert_close(got - x, want - x, 2e-5, "update")
+    assert (got - want).abs().max().item() <= 4e-7
+    # a NaN in the noise raises the flag
+    eps[0, 0, 0, 0, 0] = float("nan")
+    op.langevin_step(x.clone(), y, x0, p, None, eps=eps, nan_flag=flag)
+    assert flag.item() == 1
+
+
+def test_sample_with_torch_noise_through_the_adjoint(dev):
+    """MCMCSampler.sample, torch noise, 'gaussian' solver, hmc at momentum 0 (the shipped black-hole
+    algorithm): the route that hands each step's draw to the adjoint == gradient + update kernel on
+    the same generator stream."""
+    from step_amd.sampler.daps import MCMCSampler
+    op = make(dev, 6, 64)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x0 = torch.rand(5, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1
+    xt = x0 + 0.3 * torch.randn(x0.shape, device=dev, generator=gen)
+    y = op(torch.rand(1, 64, 1, 64, 64, device=dev, generator=gen) * 2 - 1)
+    tau = 0.05
+    lr = float(1e-3 * tau ** 2 / op.gradient(x0, y).abs().max())
+    out = {}
+    for fuse in (True, False):
+        mc = MCMCSampler(num_steps=8, lr=lr, tau=tau, lr_min_ratio=0.1, prior_solver="gaussian", mc_algo="hmc",
+                         momentum=0.0)
+        mc.fuse_langevin = fuse
+        mc.set_chains(generators=[torch.Generator(device=dev).manual_seed(50 + i) for i in range(5)])
+        out[fuse] = mc.sample(xt, None, x0, op, y, 0.5, 0.25)
+    assert (out[True] - x0).abs().max() > 1e-4
+    assert_close(out[True] - x0, out[False] - x0, 1e-4, "eight steps")
