@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 10 since mri_loss_grad_mc_fused; 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -355,6 +355,22 @@ int mri_loss_grad_mc(const float* x, const float* sens, int C, const float* y, i
                      int T, int R, const int32_t* rows, const int32_t* nrows, int mask_frames,
                      int max_rows, const float* chain_scale, float* loss_part, float* loss,
                      float* loss_total, float* grad, void* stream);
+
+/* The multi-coil step in ONE kernel on the pipelined transforms (round 3; NO REFERENCE COUNTERPART):
+ * a persistent workgroup owns a frame for all coils -- S_c * x is formed in registers from the strip
+ * loads (z never exists in memory), each coil's processed kept rows go to the workgroup's scratch
+ * slot, and the inverse column phase runs strip-outer / coil-inner so that sum_c conj(S_c) * A^H(2 r_c)
+ * accumulates in registers and every gradient pixel is stored once.  Same arguments and results as
+ * mri_loss_grad_mc (to fp32 rounding; C = 1 with S = 1 + 0i gives mri_loss_grad(variant 2)'s gradient
+ * bit for bit); masks of <= 64 kept rows per frame.  loss_part: float[2*B*T].
+ * ws: device scratch of mri_loss_grad_mc_fused_ws_bytes(C, B, T, max_rows) bytes (min(B*T, CUs) slots
+ * of C x 64 x 192 complex; any contents; not needed when grad is NULL); calls that share it must not
+ * overlap. */
+size_t mri_loss_grad_mc_fused_ws_bytes(int C, int B, int T, int max_rows);
+int mri_loss_grad_mc_fused(const float* x, const float* sens, int C, const float* y, int y_batch, int B,
+                           int T, int R, const int32_t* rows, const int32_t* nrows, int mask_frames,
+                           int max_rows, const float* chain_scale, float* loss_part, void* ws,
+                           size_t ws_bytes, float* loss, float* loss_total, float* grad, void* stream);
 
 /* The same operator as two streaming kernels around the SINGLE-coil step: z[f][c] = S_c * x[f]
  * ([nframes][C][2][R][R]), then mri_loss_grad on B x (T*C) frames (z as x, the multi-coil

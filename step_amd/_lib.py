@@ -105,6 +105,9 @@ SIGNATURES = {
     "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                c_p, c_p, c_p]),
+    "mri_loss_grad_mc_fused_ws_bytes": (C.c_size_t, [c_i, c_i, c_i, c_i]),
+    "mri_loss_grad_mc_fused": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
+                                     C.c_size_t, c_p, c_p, c_p, c_p]),
     "mri_coil_mul": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "mri_coil_combine": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "nufft_interp_blocks": (c_i, [c_i]),

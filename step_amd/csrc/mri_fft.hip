@@ -22,6 +22,7 @@
 #include "mri_lg2.h"
 #include "mri_lg2p.h"
 #include "mri_lg2s.h"
+#include "mri_lg2mc.h"
 
 #define MRI_R 192
 #define MRI_THREADS 512
@@ -440,6 +441,18 @@ __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2s(
     Lg2DevCtx ctx{lds};
     lg2s_body<SP>(ctx, x, y, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, part_out, unk_out,
                   grad, zs, cnt, loss, total);
+}
+
+// ------------------------------------------- multi-coil loss + gradient in one kernel (mri_lg2mc.h)
+__global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad_mcf(
+    const float* __restrict__ x, const float* __restrict__ sens, int C, const float* __restrict__ y,
+    int y_batch, const int* __restrict__ rows, const int* __restrict__ nrows, int mask_frames, int T,
+    int nframes, int nkc, const float* __restrict__ chain_scale, float* __restrict__ loss_part,
+    float* __restrict__ unk_part, float* __restrict__ grad, cf32* zs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Lg2DevCtx ctx{lds};
+    lg2mc_body(ctx, x, sens, C, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
+               loss_part, unk_part, grad, zs);
 }
 
 // ------------------------------------------------------------------------------- adjoint only
@@ -923,6 +936,46 @@ extern "C" int mri_loss_grad_split(const float* x, const float* y, int B, int T,
     else if (np == 3) { LG2S_LAUNCH(2); }
     else { LG2S_LAUNCH(3); }
 #undef LG2S_LAUNCH
+    STEP_CHECK_LAUNCH(who);
+    return STEP_OK;
+}
+
+// ------------------------------------------------------------ multi-coil step in one kernel
+static long long mcf_grid(long long nframes) {
+    const long long cus = mri_cu_count();
+    return nframes < cus ? nframes : cus;
+}
+
+extern "C" size_t mri_loss_grad_mc_fused_ws_bytes(int C, int B, int T, int max_rows) {
+    if (C <= 0 || B <= 0 || T <= 0 || max_rows > LG2_NKC_MAX) return 0;
+    return (size_t)mcf_grid((long long)B * T) * C * pick_nkc(max_rows) * MRI_R * sizeof(cf32);
+}
+
+extern "C" int mri_loss_grad_mc_fused(const float* x, const float* sens, int C, const float* y, int y_batch,
+                                      int B, int T, int R, const int32_t* rows, const int32_t* nrows,
+                                      int mask_frames, int max_rows, const float* chain_scale,
+                                      float* loss_part, void* ws, size_t ws_bytes, float* loss,
+                                      float* loss_total, float* grad, void* stream) {
+    const char* who = "mri_loss_grad_mc_fused";
+    STEP_REQUIRE(x && sens && y && loss_part && loss && C > 0, "%s: null pointer / C", who);
+    STEP_REQUIRE(y_batch == 1 || y_batch == B, "%s: measurement batch %d vs B=%d", who, y_batch, B);
+    if (int rc = mri_check(who, B, T, R, rows, nrows, mask_frames)) return rc;
+    STEP_REQUIRE(max_rows <= LG2_NKC_MAX, "%s: masks of <= %d kept rows (got %d); use mri_loss_grad_mc", who,
+                 LG2_NKC_MAX, max_rows);
+    const size_t need = mri_loss_grad_mc_fused_ws_bytes(C, B, T, max_rows);
+    STEP_REQUIRE(!grad || (ws && ws_bytes >= need), "%s: workspace of %zu bytes, %zu needed", who, ws_bytes, need);
+    STEP_REQUIRE(((uintptr_t)ws & 7) == 0, "%s: workspace must be 8-byte aligned", who);
+    const int nkc = pick_nkc(max_rows), nframes = B * T;
+    const size_t lds = lg2_lds_bytes(nkc);
+    float* unk = loss_part + (size_t)nframes;
+    const int n_unk = y_batch == 1 ? (B < LG2_UNK_PARTS ? B : LG2_UNK_PARTS) * T : 0;
+    hipStream_t s = (hipStream_t)stream;
+    step_allow_lds((const void*)k_mri_loss_grad_mcf, lds);
+    hipLaunchKernelGGL(k_mri_loss_grad_mcf, dim3((unsigned)mcf_grid(nframes)), dim3(LG2_THREADS), lds, s, x, sens, C,
+                       y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part, unk, grad,
+                       (cf32*)ws);
+    STEP_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss, loss_total);
     STEP_CHECK_LAUNCH(who);
     return STEP_OK;
 }

@@ -315,12 +315,51 @@ class MultiCoilMRI(DynamicMRI):
         self._loss_total = loss[B]
         return loss[:B], grad
 
+    # loss / gradient in ONE kernel on the pipelined transforms (mri_loss_grad_mc_fused, round 3): the coil
+    # multiply in the strip loads, the coil sum in the inverse column phase's registers.  None = whenever
+    # every mask frame keeps <= 64 rows (every shipped mode) and split_coils is not forced; False = never.
+    fused_coils = None
+
+    def _launch_fused(self, x, y, need_grad, chain_scale):
+        B, T, Cn, R = x.shape[0], self.frames, self.coils, self.resolution
+        L, dev = _lib.lib(), x.device
+        rows, nrows = self._tables(dev)
+        part = torch.empty(2 * B * T, device=dev, dtype=torch.float32)
+        loss = torch.empty(B + 1, device=dev, dtype=torch.float32)
+        grad = torch.empty_like(x) if need_grad else None
+        ws, nbytes = None, 0
+        if need_grad:
+            nbytes = L.mri_loss_grad_mc_fused_ws_bytes(Cn, B, T, self._max_rows)
+            key = ("mcf_ws", str(dev))
+            ws = self._dev_tables.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+                self._dev_tables[key] = ws
+        t0 = None
+        if self._prof is not None:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(torch.cuda.current_stream(dev))
+        rc = L.mri_loss_grad_mc_fused(x.data_ptr(), self._sens_on(dev).data_ptr(), Cn, y.data_ptr(), y.shape[0], B, T,
+                                      R, rows.data_ptr(), nrows.data_ptr(), self.mask.shape[1], self._max_rows,
+                                      _lib.ptr(chain_scale), part.data_ptr(), _lib.ptr(ws), nbytes, loss.data_ptr(),
+                                      loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record(torch.cuda.current_stream(dev))
+            self._prof.setdefault("mri_loss_grad_mc", []).append((t0, t1))
+        _lib.check(rc, "mri_loss_grad_mc_fused")
+        self._loss_total = loss[B]
+        return loss[:B], grad
+
     def _launch_loss_grad(self, x, y, need_grad, chain_scale):
         B, T = self._dims(x)
         y = _f32c(y, x.device)
         want = (T, self.coils, 2, self.resolution, self.resolution)
         if y.dim() != 6 or tuple(y.shape[1:]) != want or y.shape[0] not in (1, B):
             raise ValueError("measurement shape %s, expected [1 or %d, %s]" % (tuple(y.shape), B, want))
+        fused = (self.split_coils is None and self._max_rows <= 64) if self.fused_coils is None else self.fused_coils
+        if fused:
+            return self._launch_fused(x, y, need_grad, chain_scale)
         split = self.coils >= 3 if self.split_coils is None else self.split_coils
         if split and B * T <= 65535:
             return self._launch_split(x, y, need_grad, chain_scale)
