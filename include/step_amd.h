@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 10 since mri_loss_grad_mc_fused; 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 11 since mri_step_update; 10 since mri_loss_grad_mc_fused; 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -340,6 +340,23 @@ int mri_loss_grad_split(const float* x, const float* y, int B, int T, int R, con
                         const int32_t* nrows, int mask_frames, int max_rows,
                         const float* chain_scale, int parts, void* ws, size_t ws_bytes, float* loss,
                         float* loss_total, float* grad, void* stream);
+
+/* One step of the MRI data-consistency loop with the STATE UPDATE inside the kernel: mri_loss_grad's
+ * pipelined kernel applies the update where its inverse column phase would have stored the gradient
+ * (x and x0hat are read at a thread's output pixels while its last pass runs; the gradient never
+ * reaches HBM).  x: the state [B][T][2][R][R], evaluated and then updated in place; one measurement for
+ * all chains (y: [T][2][R][R]); masks of <= 64 kept rows per frame.
+ *   mode 1: MCMCSampler.optimize (daps.py:210-223):  x -= p->lr (g + (x - x0hat) p->inv_sigma2)
+ *   mode 2 / 3: the Langevin / momentum-free HMC step of MCMCSampler.sample (daps.py:93-104, :135-144)
+ *     for the 'gaussian' prior solver, score = -g p->inv_tau2 + (x0hat - x) p->inv_sigma2, with the
+ *     noise READ from `eps` (laid out like x, e.g. the reference's torch.randn_like, daps.py:192)
+ * -- the results of mri_loss_grad followed by mcmc_update(algo 2 / 0 / 1, xt = x0hat, prior = NULL).
+ * loss [B] / loss_total: the loss at the OLD x; loss_part: float[2*B*T]; nan_flag (may be NULL, modes
+ * 2 / 3): set to 1 when an updated element is NaN.  p: HOST pointer, read during the call. */
+int mri_step_update(float* x, const float* x0hat, const float* eps, const float* y, int B, int T, int R,
+                    const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows, int mode,
+                    const mcmc_params_t* p, float* loss_part, float* loss, float* loss_total,
+                    int32_t* nan_flag, void* stream);
 
 /* Multi-coil variants -- NO REFERENCE COUNTERPART (the reference operator is single-coil,
  * dynamic_mri.py:42-48; BASELINE.json names the coil-sensitivity multiply): y_c = M * FFT2(fftshift(

@@ -102,6 +102,8 @@ SIGNATURES = {
     "mri_loss_grad_split_ws_bytes": (C.c_size_t, [c_i, c_i, c_i, c_i]),
     "mri_loss_grad_split": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p, C.c_size_t,
                                   c_p, c_p, c_p, c_p]),
+    "mri_step_update": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, C.POINTER(mcmc_params_t),
+                              c_p, c_p, c_p, c_p, c_p]),
     "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                c_p, c_p, c_p]),

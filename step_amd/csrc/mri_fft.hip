@@ -400,6 +400,10 @@ struct Lg2DevCtx {
     // phase marker of the body: a no-op here (scripts/probes/mri_timing.hip builds the body over
     // a context that records timestamps)
     __device__ __forceinline__ void tick(int, int) const {}
+    // the NaN flag of the in-kernel state update: one atomic per wave that saw a NaN, none once it is up
+    __device__ __forceinline__ void raise_flag(int* f) const {
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(f, 1);
+    }
     __device__ __forceinline__ cf32 cos_sin_2pi_over_192(int e) const {
         float sn, cn;
         sincospif((float)e * (1.0f / 96.0f), &sn, &cn);
@@ -417,6 +421,19 @@ __global__ __launch_bounds__(LG2_THREADS) void k_mri_loss_grad2(
     Lg2DevCtx ctx{lds};
     lg2_body<YQ>(ctx, x, y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale,
                  loss_part, unk_part, grad);
+}
+
+// the pipelined kernel with the state update in place of the gradient store (Lg2Upd, mri_lg2.h)
+template <int UPD>
+__global__ __launch_bounds__(LG2_THREADS) void k_mri_step_upd(
+    const float* x, const float* __restrict__ y, const int* __restrict__ rows,
+    const int* __restrict__ nrows, int mask_frames, int T, int nframes, int nkc,
+    const float* __restrict__ chain_scale, float* __restrict__ loss_part, float* __restrict__ unk_part,
+    Lg2Upd up) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Lg2DevCtx ctx{lds};
+    lg2_body<false, UPD>(ctx, x, y, 1, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part,
+                         unk_part, nullptr, up);
 }
 
 // ------------------------------------------- loss + gradient, persistent pipelined kernel (mri_lg2p.h)
@@ -974,6 +991,43 @@ extern "C" int mri_loss_grad_mc_fused(const float* x, const float* sens, int C, 
     hipLaunchKernelGGL(k_mri_loss_grad_mcf, dim3((unsigned)mcf_grid(nframes)), dim3(LG2_THREADS), lds, s, x, sens, C,
                        y, y_batch, rows, nrows, mask_frames, T, nframes, nkc, chain_scale, loss_part, unk, grad,
                        (cf32*)ws);
+    STEP_CHECK_LAUNCH(who);
+    hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss, loss_total);
+    STEP_CHECK_LAUNCH(who);
+    return STEP_OK;
+}
+
+// ------------------------------------------------------------ the step with the state update inside
+// mri_loss_grad(variant 2) with MCMCSampler.optimize's update (mode 1), or the Langevin (2) / momentum-free HMC
+// (3) step of MCMCSampler.sample with the noise read from `eps`, applied by the inverse column phase where
+// it would have stored the gradient: the gradient never reaches HBM.
+extern "C" int mri_step_update(float* x, const float* x0hat, const float* eps, const float* y, int B, int T, int R,
+                               const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
+                               int mode, const mcmc_params_t* p, float* loss_part, float* loss,
+                               float* loss_total, int32_t* nan_flag, void* stream) {
+    const char* who = "mri_step_update";
+    STEP_REQUIRE(x && x0hat && y && p && loss_part && loss, "%s: null pointer", who);
+    STEP_REQUIRE(mode >= 1 && mode <= 3, "%s: mode %d (1 optimize, 2 langevin, 3 hmc at momentum 0)", who, mode);
+    STEP_REQUIRE(mode == 1 || eps, "%s: langevin / hmc read their noise from `eps`", who);
+    STEP_REQUIRE(mode != 3 || p->momentum == 0.f, "%s: hmc with momentum %g carries a velocity; use mri_loss_grad + mcmc_update",
+                 who, (double)p->momentum);
+    STEP_REQUIRE(x != x0hat, "%s: x and x0hat must not share storage", who);
+    if (int rc = mri_check(who, B, T, R, rows, nrows, mask_frames)) return rc;
+    STEP_REQUIRE(max_rows <= LG2_NKC_MAX, "%s: masks of <= %d kept rows (got %d)", who, LG2_NKC_MAX, max_rows);
+    const int nkc = pick_nkc(max_rows), nframes = B * T;
+    const size_t lds = lg2_lds_bytes(nkc);
+    float* unk = loss_part + (size_t)nframes;
+    const int n_unk = (B < LG2_UNK_PARTS ? B : LG2_UNK_PARTS) * T;
+    const Lg2Upd up{x, x0hat, eps, p->lr, p->inv_sigma2, p->inv_tau2, p->sqrt_lr, p->sqrt_2lr, p->noise_scale, nan_flag};
+    hipStream_t s = (hipStream_t)stream;
+#define MRI_UPD_LAUNCH(M)                                                                              \
+    step_allow_lds((const void*)k_mri_step_upd<M>, lds);                                               \
+    hipLaunchKernelGGL(k_mri_step_upd<M>, dim3(nframes), dim3(LG2_THREADS), lds, s, x, y, rows, nrows, \
+                       mask_frames, T, nframes, nkc, nullptr, loss_part, unk, up)
+    if (mode == 1) { MRI_UPD_LAUNCH(1); }
+    else if (mode == 2) { MRI_UPD_LAUNCH(2); }
+    else { MRI_UPD_LAUNCH(3); }
+#undef MRI_UPD_LAUNCH
     STEP_CHECK_LAUNCH(who);
     hipLaunchKernelGGL(k_mri_loss_finish, dim3(1), dim3(256), 0, s, loss_part, unk, n_unk, B, T, loss, loss_total);
     STEP_CHECK_LAUNCH(who);

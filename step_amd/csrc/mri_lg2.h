@@ -245,12 +245,36 @@ LG2_DEV void lg2_row_phase(const Ctx& ctx, cf32* Rk, const cf32* tw, const int* 
 // YQ: loss_part[frame] = sum |A(x) - y|^2 over all rows.  !YQ (y_batch == 1): loss_part[frame]
 // covers the kept rows, and unk_part[b * T + t], b < min(B, 16), the b-th share of the masked-out
 // rows of measurement frame t (every chain's loss gets all shares: the caller adds them up).
-template <bool YQ, class Ctx>
+// The state update applied where the inverse column phase would have stored the gradient (UPD > 0:
+// `grad` is not written): x (the very state the step was evaluated at) and x0hat are read at the
+// thread's twelve output pixels while its last pass runs, x is stored.
+//   UPD 1: MCMCSampler.optimize, daps.py:210-223:  x -= lr (g + (x - x0hat) / sigma^2)
+//   UPD 2 / 3: the Langevin / momentum-free HMC step of MCMCSampler.sample (daps.py:93-104, :135-144) for
+//   the 'gaussian' prior solver, score = -g / tau^2 + (x0hat - x) / sigma^2, with the noise READ from
+//   `eps` (laid out like x): the arithmetic of mcmc_elem_a<0 / 1> (mcmc_elem.h) with xt = x0hat, no prior.
+struct Lg2Upd {
+    float* x;            // [nframes][2][R][R]: the state, updated in place
+    const float* x0;     // x0hat
+    const float* eps;    // UPD >= 2
+    float lr, inv_sigma2, inv_tau2, sqrt_lr, sqrt_2lr, noise_scale;
+    int* nan_flag;       // UPD >= 2, may be null: set to 1 when an updated element is NaN
+};
+
+template <int UPD>
+LG2_DEV float lg2_upd_elem(float xi, float g, float xh, float e, const Lg2Upd& p) {
+    if (UPD == 1) return xi - p.lr * (g + (xi - xh) * p.inv_sigma2);
+    const float s = -g * p.inv_tau2 + (xh - xi) * p.inv_sigma2 + 0.f;
+    if (UPD == 2) return xi + p.lr * s + p.sqrt_2lr * e;
+    const float v = 0.f * 0.f + p.sqrt_lr * s + p.noise_scale * e;
+    return xi + v * p.sqrt_lr;
+}
+
+template <bool YQ, int UPD = 0, class Ctx = void>
 LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* __restrict__ y,
                       int y_batch, const int* __restrict__ rows, const int* __restrict__ nrows,
                       int mask_frames, int T, int nframes, int nkc,
                       const float* __restrict__ chain_scale, float* __restrict__ loss_part,
-                      float* __restrict__ unk_part, float* __restrict__ grad) {
+                      float* __restrict__ unk_part, float* __restrict__ grad, Lg2Upd up = Lg2Upd()) {
     constexpr int R = LG2_R, SW = LG2_SW, NS = LG2_NS, RS = LG2_RS, Q = LG2_R / 4;
     const Lg2Lds L = lg2_carve(ctx.lds(), nkc);
     const int tid = ctx.tid();
@@ -453,14 +477,17 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             }
         }
         lg2_row_phase<LG2_THREADS>(ctx, L.Rk, L.tw, L.rowl, rows + (size_t)mf * R, nk, yr, yi, cs2,
-                                   grad != nullptr, frame, acc);
-        if (grad) {
+                                   UPD != 0 || grad != nullptr, frame, acc);
+        bool bad = false;
+        if (UPD != 0 || grad) {
             ctx.sync();
             ctx.tick(5, frame);
 
             // ------------------------------------------------------------ inverse column phase
-            float* dr = grad + (size_t)frame * fsz;
+            float* dr = (UPD ? up.x : grad) + (size_t)frame * fsz;
             float* di = dr + R * R;
+            const float* hr = UPD ? up.x0 + (size_t)frame * fsz : nullptr;
+            const float* er = UPD >= 2 ? up.eps + (size_t)frame * fsz : nullptr;
             LG2_IDS(t3)
             cf32 a[16], u[12];
 #define LG2_INV_A(strip)                                                              \
@@ -490,14 +517,36 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             for (int s = 0; s < NS; ++s) {
                 if (s + 1 < NS) { LG2_INV_A(s + 1) }
                 LG2_FENCE();
-                fft192_pass_b<1>(u);
                 unsigned ob = offB + (unsigned)s * (SW * 4u);
                 LG2_OPAQUE(ob);
+                if (UPD) {
+                    // state, x0hat (and noise) of the twelve output pixels travel under the last pass
+                    cf32 xo[12], xh[12], ev[12];
+#pragma unroll
+                    for (int d = 0; d < 12; ++d) {
+                        const unsigned o = ob + (unsigned)d * (16u * R * 4u);
+                        xo[d] = c_make(lg2_ld(dr, o), lg2_ld(di, o));
+                        xh[d] = c_make(lg2_ld(hr, o), lg2_ld(hr + R * R, o));
+                        ev[d] = UPD >= 2 ? c_make(lg2_ld(er, o), lg2_ld(er + R * R, o)) : c_make(0.f, 0.f);
+                    }
+                    fft192_pass_b<1>(u);
+#pragma unroll
+                    for (int d = 0; d < 12; ++d) {
+                        const unsigned o = ob + (unsigned)d * (16u * R * 4u);
+                        const float nr_ = lg2_upd_elem<UPD>(xo[d].x, u[d].x, xh[d].x, ev[d].x, up);
+                        const float ni_ = lg2_upd_elem<UPD>(xo[d].y, u[d].y, xh[d].y, ev[d].y, up);
+                        bad |= (nr_ != nr_) | (ni_ != ni_);
+                        lg2_st(dr, o, nr_);
+                        lg2_st(di, o, ni_);
+                    }
+                } else {
+                fft192_pass_b<1>(u);
 #pragma unroll
                 for (int d = 0; d < 12; ++d) {
                     const unsigned o = ob + (unsigned)d * (16u * R * 4u);
                     lg2_st(dr, o, u[d].x);
                     lg2_st(di, o, u[d].y);
+                }
                 }
                 if (s + 1 < NS) {
                     ctx.sync();
@@ -512,6 +561,7 @@ LG2_DEV void lg2_body(const Ctx& ctx, const float* __restrict__ x, const float* 
             }
 #undef LG2_INV_A
         }
+        if (UPD >= 2 && up.nan_flag && bad) ctx.raise_flag(up.nan_flag);
         ctx.tick(6, frame);
         const float tot = lg2_block_sum(ctx, acc, L.red);
         if (tid == 0) loss_part[frame] = tot;

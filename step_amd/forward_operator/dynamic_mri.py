@@ -176,6 +176,64 @@ class DynamicMRI(Operator):
         self._loss_total = loss[B]           # scalar sum over the chains, summed by the finish kernel
         return loss[:B], grad
 
+    # ------------------------------------------------------------------ the step with the update inside
+    @property
+    def has_descent_step(self):
+        """descent_step / langevin_step(eps=...) live in the pipelined kernel: masks of <= 64 kept rows."""
+        return type(self) is DynamicMRI and self._max_rows <= 64 and int(self.resolution) == 192
+
+    has_langevin_step = has_descent_step
+    langevin_draws_noise = False     # langevin_step needs `eps`: no in-kernel generator here
+
+    def prefers_langevin_step(self, batch):
+        return self.has_langevin_step
+
+    def _step_update(self, x, y, x0hat, eps, mode, params, nan_flag, return_loss, who):
+        import ctypes as C
+        B, T = self._dims(x)
+        if (x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != 'cuda' or x.requires_grad):
+            raise ValueError("%s needs a contiguous fp32 CUDA state without autograd history" % who)
+        x0 = x0hat.detach()
+        if x0.dtype != torch.float32 or not x0.is_contiguous() or x0.shape != x.shape or x0.device != x.device:
+            x0 = x0.to(device=x.device, dtype=torch.float32).expand_as(x).contiguous()
+        if x0.data_ptr() == x.data_ptr():
+            raise ValueError("%s: x and x0hat must not share storage" % who)
+        y = _f32c(y, x.device)
+        if y.dim() != 5 or y.shape[0] != 1 or y.shape[1:] != x.shape[1:]:
+            raise ValueError("%s takes one measurement for all chains, got %s" % (who, tuple(y.shape)))
+        if eps is not None and (eps.dtype != torch.float32 or eps.shape != x.shape or eps.device != x.device
+                                or not eps.is_contiguous()):
+            raise ValueError("%s: eps must be contiguous float32 %s on %s" % (who, tuple(x.shape), x.device))
+        rows, nrows = self._tables(x.device)
+        part = torch.empty(2 * B * T, device=x.device, dtype=torch.float32)
+        loss = torch.empty(B + 1, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().mri_step_update(x.data_ptr(), x0.data_ptr(), _lib.ptr(eps), y.data_ptr(), B, T,
+                                        self.resolution, rows.data_ptr(), nrows.data_ptr(), self.mask.shape[1],
+                                        self._max_rows, mode, C.byref(params), part.data_ptr(), loss.data_ptr(),
+                                        loss.data_ptr() + 4 * B, _lib.ptr(nan_flag), _lib.stream_of(x))
+        _lib.check(rc, "mri_step_update")
+        return loss[B] if return_loss else None
+
+    def descent_step(self, x, y, x0hat, lr, inv_sigma2, return_loss=False):
+        """One step of MCMCSampler.optimize (daps.py:210-223) in place on x:
+        ``x -= lr * (gradient(x, y) + (x - x0hat) * inv_sigma2)``, applied by the kernel's inverse column
+        phase where it would have stored the gradient (mri_step_update); -> the summed loss at the old x."""
+        p = _lib.mcmc_params_t(1.0, float(inv_sigma2), float(lr), 0.0, 0.0, 0.0, 0.0, 2)
+        return self._step_update(x, y, x0hat, None, 1, p, None, return_loss, "descent_step")
+
+    def langevin_step(self, x, y, x0hat, params, seeds=None, step=0, step_dev=None, nan_flag=None,
+                      return_loss=False, eps=None):
+        """One step of MCMCSampler.sample (daps.py:184-200) in place on x for the 'gaussian' prior solver
+        (score ``-g / tau^2 + (x0hat - x) / sigma^2``), langevin (params.algo 0) or hmc at momentum 0
+        (algo 1), with the step's noise handed over as the tensor ``eps`` (the reference's
+        ``torch.randn_like``): the kernel applies the update, the gradient never reaches HBM.  This
+        operator draws no noise itself: ``eps`` is required (``seeds`` / ``step`` are ignored)."""
+        if eps is None:
+            raise NotImplementedError("the MRI kernel reads its noise from `eps`; in-kernel Philox noise is the "
+                                      "black-hole adjoint's (use gradient + mcmc_update_philox here)")
+        return self._step_update(x, y, x0hat, eps, 2 + int(params.algo), params, nan_flag, return_loss,
+                                 "langevin_step")
+
     # ------------------------------------------------------------------ reference API
     def __call__(self, x):
         # [B, T, C, H, W] -> masked k-space, same layout (dynamic_mri.py:42-48)

@@ -296,6 +296,7 @@ class MCMCSampler(nn.Module):
         in_adjoint = (self.fuse_langevin and not record and self.prior_solver == 'gaussian'
                       and (self.mc_algo == 'langevin' or self.momentum == 0)
                       and getattr(operator, 'has_langevin_step', False)
+                      and getattr(operator, 'langevin_draws_noise', True)      # the MRI kernel only reads `eps`
                       and (self.fuse_langevin == 'always' or operator.prefers_langevin_step(x.shape[0])))
         if in_adjoint:
             x0 = self._kernel_tensor(x0hat.detach(), x)

@@ -257,3 +257,69 @@ def test_split_frame_applies_to_small_batches_only(dev):
     y = op(torch.randn(1, 12, 2, 192, 192, device=dev))
     op.gradient(x, y)                                               # 12 chains: the unsplit kernel
     assert ("split_ws", str(x.device)) not in op._dev_tables
+
+
+@pytest.mark.parametrize("mode,acc,acs,B", [("same_mask", 6, 24, 3), ("same_mask", 6, 24, 30), ("split_mask", 8, 12, 5)])
+def test_step_with_the_update_inside_equals_gradient_then_update(mode, acc, acs, B, dev):
+    """mri_step_update: MCMCSampler.optimize's update and the Langevin / momentum-free HMC step of
+    MCMCSampler.sample (noise from a tensor) applied by the inverse column phase where it would have
+    stored the gradient == gradient() followed by mcmc_update with xt = x0hat and no prior tensor."""
+    import ctypes as C
+    from step_amd import _lib
+    op = make_op(mode, acc_factor=acc, num_acs_lines=acs)
+    gen = torch.Generator(device=dev).manual_seed(41 + B)
+    x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
+    x0 = x + 0.05 * torch.randn(x.shape, device=dev, generator=gen)
+    eps = torch.randn(x.shape, device=dev, generator=gen)
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)) + 0.1 * torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen)
+    op.split_frames = False
+    g, total = op.gradient(x, y, return_loss=True)
+    gmax = float(g.abs().max())
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    lr = 1e-4
+    for algo in (2, 0, 1):
+        p = _lib.mcmc_params_t(30.0 / gmax, 40.0, 0.02 / gmax if algo == 2 else lr, np.sqrt(lr), np.sqrt(2 * lr), 0.0,
+                               np.sqrt(2.0), algo)
+        want = x.clone()
+        vel = torch.zeros_like(x) if algo == 1 else None
+        rc = _lib.lib().mcmc_update(want.data_ptr(), _lib.ptr(vel), g.data_ptr(), x0.data_ptr(), None,
+                                    None if algo == 2 else eps.data_ptr(), x.numel(), C.byref(p), flag.data_ptr(),
+                                    _lib.stream_of(x))
+        _lib.check(rc, "mcmc_update")
+        got = x.clone()
+        if algo == 2:
+            got_total = op.descent_step(got, y, x0, p.lr, p.inv_sigma2, return_loss=True)
+        else:
+            got_total = op.langevin_step(got, y, x0, p, eps=eps, nan_flag=flag, return_loss=True)
+        assert_close(got_total, total, 1e-6, "loss at the old x (algo %d)" % algo)
+        assert (want - x).abs().max() > 1e-3
+        assert_close(got - x, want - x, 2e-5, "update (algo %d)" % algo)
+        assert flag.item() == 0
+    eps[0, 0, 0, 0, 0] = float("nan")
+    op.langevin_step(x.clone(), y, x0, p, eps=eps, nan_flag=flag)
+    assert flag.item() == 1
+    with pytest.raises(ValueError):
+        op.descent_step(got, y, got, 1e-3, 1.0)
+
+
+def test_mri_sampler_loops_with_and_without_the_update_inside(dev):
+    """MCMCSampler.optimize and .sample (torch noise, 'gaussian' solver, hmc at momentum 0) on the MRI
+    operator: the routes through descent_step / langevin_step(eps=...) == gradient + update kernel."""
+    from step_amd.sampler.daps import MCMCSampler
+    op = make_op("same_mask")
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x0 = torch.randn(8, 12, 2, 192, 192, device=dev, generator=gen)
+    xt = x0 + 0.3 * torch.randn(x0.shape, device=dev, generator=gen)
+    y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
+    tau = 0.1
+    lr = float(1e-3 * tau ** 2 / op.gradient(x0, y).abs().max())
+    out = {}
+    for fuse in (True, False):
+        mc = MCMCSampler(num_steps=6, lr=lr, tau=tau, lr_min_ratio=0.1, prior_solver="gaussian", mc_algo="hmc",
+                         momentum=0.0)
+        mc.fuse_langevin = mc.fuse_descent = fuse
+        mc.set_chains(generators=[torch.Generator(device=dev).manual_seed(50 + i) for i in range(8)])
+        out[fuse] = (mc.sample(xt, None, x0, op, y, 0.5, 0.25), mc.optimize(x0, op, y, 0.5, 0.25))
+    for k, name in ((0, "sample"), (1, "optimize")):
+        assert (out[True][k] - x0).abs().max() > 1e-5
+        assert_close(out[True][k] - x0, out[False][k] - x0, 1e-4, name)
