@@ -415,7 +415,11 @@ class MultiCoilMRI(DynamicMRI):
         want = (T, self.coils, 2, self.resolution, self.resolution)
         if y.dim() != 6 or tuple(y.shape[1:]) != want or y.shape[0] not in (1, B):
             raise ValueError("measurement shape %s, expected [1 or %d, %s]" % (tuple(y.shape), B, want))
-        fused = (self.split_coils is None and self._max_rows <= 64) if self.fused_coils is None else self.fused_coils
+        # one kernel per frame for all coils pays once the frames alone fill most of the chip; below
+        # that (scripts/kbench_mri_coils.py: 4 chains x 8 coils 0.34 ms fused, 0.14 ms split) the split
+        # path's B x T x C single-coil frames spread over the idle CUs
+        fused = (self.split_coils is None and self._max_rows <= 64 and (self.coils == 1 or B * T >= 144)) \
+            if self.fused_coils is None else self.fused_coils
         if fused:
             return self._launch_fused(x, y, need_grad, chain_scale)
         split = self.coils >= 3 if self.split_coils is None else self.split_coils
