@@ -56,10 +56,12 @@ def parse():
                    help="untimed steps before the warm-up until this much wall time has passed (clock ramp)")
     p.add_argument("--dry-run", action="store_true",
                    help="rank plumbing only (gloo, no GPU, no kernels): launch, barrier, MAX-reduce, JSON line")
-    p.add_argument("--barrier", default="gloo", choices=["gloo", "rccl"],
-                   help="what the barriers that bracket the timed region run on (N > 1): a host-side gloo group "
-                        "(default: no kernel lands on the GPU between the warm-up and the first timed step) or the "
-                        "RCCL process group")
+    p.add_argument("--barrier", default="rccl", choices=["gloo", "rccl"],
+                   help="what the barriers that bracket the timed region run on (N > 1): the RCCL process group "
+                        "(default) or a host-side gloo group.  Measured on one box at world 1 "
+                        "(profiles/r03_torchrun_vs_bare.txt): both within 1 %% of the bare run -- each rank's clock "
+                        "stops BEFORE the closing barrier either way -- so the default is the one that needs no "
+                        "second rendezvous")
     p.add_argument("--no-small-batches", action="store_true",
                    help="skip the extra B = 8 / B = 1 and sampler-loop measurements of the default blackhole run")
     return p.parse_args()
@@ -327,7 +329,12 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         if a.barrier == "gloo":
-            side = dist.new_group(backend="gloo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the ranks meet on the loopback
+            try:
+                side = dist.new_group(backend="gloo")
+            except Exception as e:                               # no host-side group: the RCCL barriers do
+                print("bench.py: gloo group unavailable (%s); bracket barriers on RCCL" % (e,), file=sys.stderr)
+                side = None
         if a.gpus != world and rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (a.gpus, world, world),
                   file=sys.stderr)
