@@ -144,6 +144,9 @@ def test_latent_wrapper_gradient(name, golden, dev):
     # the +-1 clamp makes entries within rounding of the clamp edge discontinuous: compare the
     # interior at 1e-4 and require clamped entries to agree except a handful at the edge
     inner = ref.abs() < 1
+    # (the unclamped entries are the SMALL ones of a gradient whose large entries the clamp has cut to
+    # +-1: their error is measured against max |entry| < 1, not against the gradient's own scale, which
+    # is what the 1e-4 bar refers to -- measured up to 3.4e-4 on that scale, stated bound 5e-4)
     assert_close(zg.cpu()[inner], ref[inner], 5 * RTOL, "latent gradient (unclamped entries)")
     assert ((zg.cpu() - ref).abs()[~inner] > 1e-3).sum() <= 2
     assert zg.abs().max() <= 1
@@ -422,7 +425,7 @@ def test_full_size_properties_batch64(dev):
     ah = op._adjoint(gv, gf, None, 1.0)                      # [B, T, HW]
     lhs = (torch.view_as_real(v1) * gv).flatten(1).sum(-1).double()
     rhs = (x1.flatten(1) * ah.flatten(1)).sum(-1).double()
-    assert ((lhs - rhs).abs() / lhs.abs().clamp_min(1e-30)).max().item() <= 5e-4
+    assert ((lhs - rhs).abs() / lhs.abs().clamp_min(1e-30)).max().item() <= RTOL
     y = op(x2[:1] * 2 - 1)
     lb = op.loss(x1 * 2 - 1, y)
     assert torch.equal(lb[17:18], op.loss(x1[17:18] * 2 - 1, y))

@@ -10,8 +10,12 @@ from tests.toy_model import ToyModel
 
 pytestmark = pytest.mark.gpu
 
-# a few steps of a stiff chain amplify the 1e-7 rounding differences of each step
-TRAJ_TOL = 5 * RTOL
+# Trajectories hold the common 1e-4 bar (round 3: measured, every case but one).  The one exception is
+# the stiff latent chain at the shipped black-hole step size (tau = 0.021: the data term is 2 300 x the
+# gradient, six steps through the decoder and the +-1 clamp amplify each step's 1e-7 rounding): 2.5e-4
+# measured, its own stated bound 3e-4.
+TRAJ_TOL = RTOL
+TRAJ_TOL_CASE = {"hmc_exact_latent": 3 * RTOL}
 
 
 class Replay:
@@ -66,8 +70,9 @@ def test_sample_matches_reference_trajectory(case, nan_check, setup, dev):
         out = sampler.sample(xt, model, start, oper, y, float(m["sigma"]), float(m["ratio"]),
                              record=True)
     traj = sampler.trajectory.compile().tensor_data["xi"]
-    assert_close(traj, m[case + "_traj"], TRAJ_TOL, case + " trajectory")
-    assert_close(out, m[case + "_result"], TRAJ_TOL, case + " result")
+    tol = TRAJ_TOL_CASE.get(case, TRAJ_TOL)
+    assert_close(traj, m[case + "_traj"], tol, case + " trajectory")
+    assert_close(out, m[case + "_result"], tol, case + " result")
 
 
 def test_metropolis_hastings_and_optimize(setup, dev):
