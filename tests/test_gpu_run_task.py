@@ -79,3 +79,18 @@ def test_run_task_variants(task, extra, dev):
                            "--diffusion-steps", "2"] + extra)
     assert len(stats) == 1 and stats[0]["finite"] and stats[0]["samples"] == 3
     assert stats[0]["metric_min"] == stats[0]["metric_min"]                 # not NaN
+
+
+@pytest.mark.parametrize("task,extra", [("blackhole", []), ("mri", []), ("mri", ["--pixel-space", "--prior-solver", "gaussian"]),
+                                        ("blackhole", ["--pixel-space", "--prior-solver", "gaussian", "--noise", "torch"])])
+def test_run_task_at_the_per_gpu_batches_of_configs_4_and_5(task, extra, dev):
+    """BASELINE configs 4 / 5 on one of 8 GPUs: 64 / 8 = 8 black-hole chains and 32 / 8 = 4 MRI chains in
+    ONE batch (the batches at which the two-launch black-hole step and the shared-frame MRI kernel run),
+    at the shipped MCMC settings with a shortened annealing schedule; and the pixel-space routes, whose
+    steps are the operators' in-kernel updates (descent_step / langevin_step)."""
+    from step_amd import run_task
+    n = 8 if task == "blackhole" else 4
+    stats = run_task.main(["--task", task, "--num-samples", str(n), "--max-batch", str(n), "--annealing-steps", "3",
+                           "--mcmc-steps", "12", "--diffusion-steps", "2"] + extra)
+    assert len(stats) == 1 and stats[0]["finite"] and stats[0]["samples"] == n
+    assert stats[0]["metric_min"] == stats[0]["metric_min"]
