@@ -32,7 +32,7 @@ extern "C" {
 #define STEP_E_LAUNCH     -2   /* hip launch error (hipGetLastError text in step_last_error) */
 
 const char* step_last_error(void);
-int         step_abi_version(void);   /* 11 since mri_step_update; 10 since mri_loss_grad_mc_fused; 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
+int         step_abi_version(void);   /* 12 since mri_*_any; 11 since mri_step_update; 10 since mri_loss_grad_mc_fused; 9 since bh_update_t carries `eps`; 8 since mri_loss_grad_split; 7 since nufft_plan_t carries the lane-per-chain spread lists; 6 since it carries the owner bins; 5 since bh_update_t carries the Langevin step and mcmc_update_philox takes `quad_w`; 4 since bh_loss_grad_sep3 takes `update` (3: mri_loss_grad `variant`, bh_weights_t `cphase_form`) */
 
 /* ------------------------------------------------------------------ host-side tables */
 
@@ -357,6 +357,25 @@ int mri_step_update(float* x, const float* x0hat, const float* eps, const float*
                     const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows, int mode,
                     const mcmc_params_t* p, float* loss_part, float* loss, float* loss_total,
                     int32_t* nan_flag, void* stream);
+
+/* The dynamic-MRI operator at ANY frame size H x W, 2 .. 1024 each (round 3; csrc/mri_any.hip): the reference's
+ * operator takes any `resolution` (forward_operator/dynamic_mri.py:9) and any frame width (its mask broadcasts
+ * over the last axis, :15,24,35,48); the tuned entry points above are built for 192 x 192 only and refuse
+ * other sizes.  Same reference lines, argument meaning and results (to fp32 rounding) as mri_forward
+ * (dynamic_mri.py:42-48), mri_adjoint (its vector-Jacobian product) and mri_loss_grad (base.py:40-49;
+ * chain_scale, loss, loss_total, grad as there, grad may be NULL), with rows = int32[mask_frames][H] and any
+ * number of kept rows.  Mixed-radix passes over LDS, three kernels per call; the kept k_y rows cross `ws`
+ * (device, 16-byte aligned, mri_any_ws_bytes(B, T, H, W, max_rows) bytes, any contents; calls that share it
+ * must not overlap).  mri_any_ws_bytes returns 0 for sizes outside the limits. */
+size_t mri_any_ws_bytes(int B, int T, int H, int W, int max_rows);
+int mri_forward_any(const float* x, int B, int T, int H, int W, const int32_t* rows, const int32_t* nrows,
+                    int mask_frames, int max_rows, void* ws, size_t ws_bytes, float* out, void* stream);
+int mri_adjoint_any(const float* g, int B, int T, int H, int W, const int32_t* rows, const int32_t* nrows,
+                    int mask_frames, int max_rows, void* ws, size_t ws_bytes, float* out, void* stream);
+int mri_loss_grad_any(const float* x, const float* y, int y_batch, int B, int T, int H, int W,
+                      const int32_t* rows, const int32_t* nrows, int mask_frames, int max_rows,
+                      const float* chain_scale, void* ws, size_t ws_bytes, float* loss, float* loss_total,
+                      float* grad, void* stream);
 
 /* Multi-coil variants -- NO REFERENCE COUNTERPART (the reference operator is single-coil,
  * dynamic_mri.py:42-48; BASELINE.json names the coil-sensitivity multiply): y_c = M * FFT2(fftshift(

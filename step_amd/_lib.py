@@ -104,6 +104,11 @@ SIGNATURES = {
                                   c_p, c_p, c_p, c_p]),
     "mri_step_update": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, C.POINTER(mcmc_params_t),
                               c_p, c_p, c_p, c_p, c_p]),
+    "mri_any_ws_bytes": (C.c_size_t, [c_i, c_i, c_i, c_i, c_i]),
+    "mri_forward_any": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, C.c_size_t, c_p, c_p]),
+    "mri_adjoint_any": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, C.c_size_t, c_p, c_p]),
+    "mri_loss_grad_any": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, C.c_size_t,
+                                c_p, c_p, c_p, c_p]),
     "mri_forward_mc": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "mri_loss_grad_mc": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p,
                                c_p, c_p, c_p]),

@@ -22,7 +22,7 @@ void step_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* step_last_error(void) { return g_err; }
-extern "C" int step_abi_version(void) { return 11; }   // 11: mri_step_update; 10: mri_loss_grad_mc_fused; 9: bh_update_t.eps; 8: mri_loss_grad_split; 7: nufft_plan_t lane-per-chain spread lists; 6: nufft_plan_t owner bins, nufft_fwd_grid / nufft_inv_grid; 5: bh_update_t.mcmc, mcmc_update_philox quad_w; 4: bh_loss_grad_sep3 takes `update`
+extern "C" int step_abi_version(void) { return 12; }   // 12: mri_*_any; 11: mri_step_update; 10: mri_loss_grad_mc_fused; 9: bh_update_t.eps; 8: mri_loss_grad_split; 7: nufft_plan_t lane-per-chain spread lists; 6: nufft_plan_t owner bins, nufft_fwd_grid / nufft_inv_grid; 5: bh_update_t.mcmc, mcmc_update_philox quad_w; 4: bh_loss_grad_sep3 takes `update`
 
 #define REQ(cond, ...)                      \
     do {                                    \

@@ -60,12 +60,6 @@ class DynamicMRI(Operator):
         self.acc_factor = acc_factor
         if mode not in _MODES:
             raise ValueError('Unknown mode: {}'.format(mode))
-        if int(resolution) != 192:
-            # the masks (host tables) exist at any size, the kernels for R = 192 (the shipped
-            # configuration) only: say so here, not at the first call
-            import warnings
-            warnings.warn("step_amd DynamicMRI: the kernels are built for resolution=192 only; with "
-                          "resolution=%r the mask is available, __call__ / loss / gradient will raise" % (resolution,))
         self.mode, self.resolution, self.frames = mode, resolution, frames
         mf = 1 if mode == 'same_mask' else frames
         m = np.zeros((mf, resolution), np.float32)
@@ -107,11 +101,32 @@ class DynamicMRI(Operator):
                                      torch.from_numpy(self._nrows_host).to(device))
         return self._dev_tables[key]
 
+    # Frames other than 192 x 192 (the shipped configuration, for which the tuned kernels are built) run on the
+    # mixed-radix kernels of csrc/mri_any.hip: any resolution 2 .. 1024, any frame width (the reference's mask
+    # broadcasts over the last axis).  True sends 192 x 192 there too (tests: an independent implementation).
+    generic_kernels = False
+    any_width = True         # MultiCoilMRI (192 x 192 kernels only) turns this off
+
+    def _generic(self, x):
+        return self.generic_kernels or x.shape[3] != 192 or x.shape[4] != 192
+
+    def _any_ws(self, x):
+        B, T, H, W = x.shape[0], x.shape[1], x.shape[3], x.shape[4]
+        nb = _lib.lib().mri_any_ws_bytes(B, T, H, W, self._max_rows)
+        if nb == 0:
+            raise ValueError("mri operator: frames of %d x %d are outside the kernels' range (2 .. 1024)" % (H, W))
+        key = ("any_ws", str(x.device))
+        ws = self._dev_tables.get(key)
+        if ws is None or ws.numel() < nb:
+            ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
+            self._dev_tables[key] = ws
+        return ws
+
     def _dims(self, x):
         if x.dim() != 5 or x.shape[2] != 2 or x.shape[3] != self.resolution \
-                or x.shape[4] != self.resolution:
-            raise ValueError("mri operator expects [B, T, 2, %d, %d], got %s"
-                             % (self.resolution, self.resolution, tuple(x.shape)))
+                or (x.shape[4] != self.resolution and not self.any_width):
+            raise ValueError("mri operator expects [B, T, 2, %d, %s], got %s"
+                             % (self.resolution, "W" if self.any_width else self.resolution, tuple(x.shape)))
         mf = self.mask.shape[1]
         if mf != 1 and x.shape[1] != mf:
             raise ValueError("mask has %d frames, input has %d" % (mf, x.shape[1]))
@@ -121,6 +136,13 @@ class DynamicMRI(Operator):
         B, T = self._dims(x)
         rows, nrows = self._tables(x.device)
         out = torch.empty_like(x)
+        if self._generic(x):
+            ws = self._any_ws(x)
+            rc = _lib.lib().mri_forward_any(x.data_ptr(), B, T, x.shape[3], x.shape[4], rows.data_ptr(),
+                                            nrows.data_ptr(), self.mask.shape[1], self._max_rows, ws.data_ptr(),
+                                            ws.numel(), out.data_ptr(), _lib.stream_of(x))
+            _lib.check(rc, "mri_forward_any")
+            return out
         rc = _lib.lib().mri_forward(x.data_ptr(), B, T, self.resolution, rows.data_ptr(),
                                     nrows.data_ptr(), self.mask.shape[1], self._max_rows,
                                     out.data_ptr(), _lib.stream_of(x))
@@ -131,6 +153,13 @@ class DynamicMRI(Operator):
         B, T = self._dims(g)
         rows, nrows = self._tables(g.device)
         out = torch.empty_like(g)
+        if self._generic(g):
+            ws = self._any_ws(g)
+            rc = _lib.lib().mri_adjoint_any(g.data_ptr(), B, T, g.shape[3], g.shape[4], rows.data_ptr(),
+                                            nrows.data_ptr(), self.mask.shape[1], self._max_rows, ws.data_ptr(),
+                                            ws.numel(), out.data_ptr(), _lib.stream_of(g))
+            _lib.check(rc, "mri_adjoint_any")
+            return out
         rc = _lib.lib().mri_adjoint(g.data_ptr(), B, T, self.resolution, rows.data_ptr(),
                                     nrows.data_ptr(), self.mask.shape[1], self._max_rows,
                                     out.data_ptr(), _lib.stream_of(g))
@@ -146,6 +175,15 @@ class DynamicMRI(Operator):
         rows, nrows = self._tables(x.device)
         loss = torch.empty(B + 1, device=x.device, dtype=torch.float32)   # [B] per chain + their sum
         grad = torch.empty_like(x) if need_grad else None
+        if self._generic(x):
+            ws = self._any_ws(x)
+            rc = _lib.lib().mri_loss_grad_any(x.data_ptr(), y.data_ptr(), y.shape[0], B, T, x.shape[3], x.shape[4],
+                                              rows.data_ptr(), nrows.data_ptr(), self.mask.shape[1], self._max_rows,
+                                              _lib.ptr(chain_scale), ws.data_ptr(), ws.numel(), loss.data_ptr(),
+                                              loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
+            _lib.check(rc, "mri_loss_grad_any")
+            self._loss_total = loss[B]
+            return loss[:B], grad
         ws_bytes = 0
         if y.shape[0] == 1 and self.kernel_variant == 0 and self.split_frames is not False:
             ws_bytes = _lib.lib().mri_loss_grad_split_ws_bytes(B, T, self._max_rows, int(self.split_frames or 0))
@@ -180,7 +218,8 @@ class DynamicMRI(Operator):
     @property
     def has_descent_step(self):
         """descent_step / langevin_step(eps=...) live in the pipelined kernel: masks of <= 64 kept rows."""
-        return type(self) is DynamicMRI and self._max_rows <= 64 and int(self.resolution) == 192
+        return (type(self) is DynamicMRI and self._max_rows <= 64 and int(self.resolution) == 192
+                and not self.generic_kernels)
 
     has_langevin_step = has_descent_step
     langevin_draws_noise = False     # langevin_step needs `eps`: no in-kernel generator here
@@ -191,6 +230,8 @@ class DynamicMRI(Operator):
     def _step_update(self, x, y, x0hat, eps, mode, params, nan_flag, return_loss, who):
         import ctypes as C
         B, T = self._dims(x)
+        if x.shape[3] != 192 or x.shape[4] != 192:
+            raise ValueError("%s lives in the 192 x 192 kernels; got frames of %d x %d" % (who, x.shape[3], x.shape[4]))
         if (x.dtype != torch.float32 or not x.is_contiguous() or x.device.type != 'cuda' or x.requires_grad):
             raise ValueError("%s needs a contiguous fp32 CUDA state without autograd history" % who)
         x0 = x0hat.detach()
@@ -296,6 +337,8 @@ class MultiCoilMRI(DynamicMRI):
     def __init__(self, acc_factor, mode='same_mask', resolution=192, frames=12, num_acs_lines=12,
                  sigma=0, sens=None, coils=None):
         super().__init__(acc_factor, mode, resolution, frames, num_acs_lines, sigma)
+        if int(resolution) != 192:
+            raise ValueError("mri_multicoil: the coil kernels are built for resolution=192 only (got %r)" % (resolution,))
         if sens is None:
             if not coils:
                 raise ValueError("mri_multicoil needs `sens` ([C, R, R] complex) or `coils`")
@@ -330,6 +373,7 @@ class MultiCoilMRI(DynamicMRI):
     # fused first-generation kernel: 2.41 -> 1.85 ms at 8 coils and 64 chains, 0.256 -> 0.280 ms at one
     # coil.  None = by coil count (split from 3 coils on), True / False force one or the other.
     split_coils = None
+    any_width = False
 
     def _tables_mc(self, device):
         """Row tables of the single-coil step seen as T * C frames: a per-frame mask repeats C times."""

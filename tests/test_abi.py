@@ -76,7 +76,7 @@ int main(void) {
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
-    assert _lib.lib().step_abi_version() == 11
+    assert _lib.lib().step_abi_version() == 12
 
 
 def test_host_entry_points_reject_bad_arguments():

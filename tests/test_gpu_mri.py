@@ -111,11 +111,16 @@ def test_config_batch_properties(dev):
     assert g0.abs().max().item() <= 1e-3 * g.abs().max().item()
 
 
-def test_rejects_other_resolutions(dev):
-    from step_amd.forward_operator import get_operator
-    op = get_operator("mri", acc_factor=4, mode="same_mask", resolution=64, frames=5, num_acs_lines=8)
-    with pytest.raises(RuntimeError, match="only resolution 192"):
-        op(torch.randn(1, 5, 2, 64, 64, device=dev))
+def test_tuned_entry_points_refuse_other_resolutions_through_the_abi(dev):
+    """The 192 x 192 kernels say so when handed another size (the operator sends those to mri_*_any,
+    tests/test_gpu_mri_any.py)."""
+    from step_amd import _lib
+    x = torch.zeros(1, 5, 2, 64, 64, device=dev)
+    rows = torch.zeros(1, 64, dtype=torch.int32, device=dev)
+    nrows = torch.ones(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().mri_forward(x.data_ptr(), 1, 5, 64, rows.data_ptr(), nrows.data_ptr(), 1, 1,
+                                torch.empty_like(x).data_ptr(), _lib.stream_of(x))
+    assert rc != 0 and "only resolution 192" in _lib.lib().step_last_error().decode()
 
 
 @pytest.mark.parametrize("mode,acc,acs,frames", [("split_mask", 192, 0, 12),      # one kept row in all: 11 empty frames

@@ -94,3 +94,33 @@ def test_run_task_at_the_per_gpu_batches_of_configs_4_and_5(task, extra, dev):
                            "--mcmc-steps", "12", "--diffusion-steps", "2"] + extra)
     assert len(stats) == 1 and stats[0]["finite"] and stats[0]["samples"] == n
     assert stats[0]["metric_min"] == stats[0]["metric_min"]
+
+
+def test_run_task_at_another_mri_resolution(tmp_path, dev):
+    """The reference's operator takes any `resolution` (dynamic_mri.py:9): a task file at 128 x 128 runs end to end
+    on the any-size kernels (csrc/mri_any.hip), latent and pixel-space routes."""
+    from step_amd import run_task
+    p = tmp_path / "task128.yaml"
+    p.write_text("""
+test_idx: [0]
+diffusion_wrapper:
+  name: st_diffusion
+  video_shape: [6, 2, 128, 128]
+  latent_shape: [6, 2, 32, 32]
+forward_operator:
+  name: mri
+  acc_factor: 4
+  mode: random_split_mask
+  resolution: 128
+  frames: 6
+  num_acs_lines: 16
+sampler:
+  name: 'latent_daps'
+  annealing_scheduler_config: {name: 'edm', num_steps: 3, sigma_max: 100, sigma_min: 1e-2, timestep: 'poly-7'}
+  diffusion_scheduler_config: {name: 'edm', num_steps: 2, sigma_min: 1e-5, timestep: 'poly-7'}
+  mcmc_sampler_config: {prior_solver: 'gaussian', mc_algo: 'langevin', num_steps: 4, lr: 1.2e-3, tau: 0.10, lr_min_ratio: 0.011}
+""")
+    for extra in ([], ["--pixel-space"]):
+        stats = run_task.main(["--task", "mri", "--config", str(p), "--num-samples", "3"] + extra)
+        assert len(stats) == 1 and stats[0]["finite"] and stats[0]["samples"] == 3
+        assert stats[0]["metric"] == "psnr" and stats[0]["metric_min"] == stats[0]["metric_min"]
