@@ -142,9 +142,28 @@ def cpu_baseline_blackhole(tab, reps):
     for _ in range(reps):
         orc.gradient(x, y, return_loss=True)
     dt = time.perf_counter() - t0
-    return dict(value=reps / dt, unit="chain-steps/s", cores=threads, kind="port",
-                sample="%d x oracle gradient (loss fwd + autograd bwd, reference formulation), "
-                       "B=1, 64x1x256x256, F=28" % reps)
+    out = dict(value=reps / dt, unit="chain-steps/s", cores=threads, kind="port",
+               sample="%d x oracle gradient (loss fwd + autograd bwd, reference formulation), "
+                      "B=1, 64x1x256x256, F=28" % reps)
+    out["sampler"] = cpu_sampler_leg(orc, x, y, reps, "hmc", 0.021)
+    return out
+
+
+def cpu_sampler_leg(orc, x0, y, steps, algo, tau):
+    """north_star's 'reference PyTorch-CPU operator AND sampler path': MCMCSampler.sample of the reference
+    (oracle/mcmc_oracle.py restates sampler/daps.py:178-208) driving the oracle operator on the same host cores,
+    `steps` steps of one call at the shipped algorithm with the 'gaussian' prior solver, pixel-space."""
+    from oracle.mcmc_oracle import MCMCOracle
+    mc = MCMCOracle(num_steps=steps, lr=1e-9, tau=tau, lr_min_ratio=0.015, prior_solver="gaussian", mc_algo=algo,
+                    momentum=0.0)
+    xt = x0 + 0.1 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(5))
+    t0 = time.perf_counter()
+    out = mc.sample(xt, None, x0, orc, y, 0.5, 0.0)
+    dt = time.perf_counter() - t0
+    return dict(value=x0.shape[0] * steps / dt, unit="chain-steps/s", ms_per_step=1e3 * dt / steps,
+                finite=bool(torch.isfinite(out).all()),
+                sample="%d steps of the oracle's MCMCSampler.sample (%s, gaussian prior solver, torch noise) on "
+                       "the oracle operator, B=%d, pixel-space" % (steps, algo, x0.shape[0]))
 
 
 def cpu_baseline_mri(reps):
@@ -160,8 +179,10 @@ def cpu_baseline_mri(reps):
     for _ in range(reps):
         orc.gradient(x, y, return_loss=True)
     dt = time.perf_counter() - t0
-    return dict(value=8 * reps / dt, unit="chain-steps/s", cores=threads, kind="port",
-                sample="%d x oracle gradient, B=8, 12x2x192x192, acc 6 / 24 ACS" % reps)
+    out = dict(value=8 * reps / dt, unit="chain-steps/s", cores=threads, kind="port",
+               sample="%d x oracle gradient, B=8, 12x2x192x192, acc 6 / 24 ACS" % reps)
+    out["sampler"] = cpu_sampler_leg(orc, x, y, reps, "langevin", 0.1)
+    return out
 
 
 def timed_region(step, steps, sync, barrier, reduce_max, gather):
@@ -312,6 +333,39 @@ def sampler_lines(op, y, dev, B, steps=30, reps=3):
                          note="sample_torch_noise: torch.randn_like per step (the reference's draw), handed to the "
                               "adjoint, which applies the update (langevin_step(eps=...)); sample_philox: update and "
                               "noise inside the adjoint (langevin_step); optimize: update inside the adjoint (descent_step)")
+    return out
+
+
+def sampler_lines_mri(op, y, dev, B, steps=30, reps=3):
+    """The MRI counterpart of sampler_lines: MCMCSampler.sample (langevin, the shipped MRI algorithm, torch draws
+    handed to the kernel, which applies the update) and .optimize (update inside the kernel) on pixel-space frames
+    with the 'gaussian' prior solver."""
+    from step_amd.sampler.daps import MCMCSampler
+    g = torch.Generator(device=dev).manual_seed(2000 + B)
+    x0 = torch.randn(B, 12, 2, 192, 192, device=dev, generator=g)
+    xt = x0 + 0.3 * torch.randn(x0.shape, device=dev, generator=g)
+    tau = 0.1
+    lr = float(1e-3 * tau ** 2 / op.gradient(x0, y).abs().max())
+    out = {}
+    for name in ("sample_torch_noise", "optimize"):
+        mc = MCMCSampler(num_steps=steps, lr=lr, tau=tau, lr_min_ratio=0.011, prior_solver="gaussian",
+                         mc_algo="langevin")
+        run = (lambda: mc.optimize(x0, op, y, 0.5, 0.0)) if name == "optimize" else \
+              (lambda: mc.sample(xt, None, x0, op, y, 0.5, 0.0))
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (reps * steps) * 1e3
+        assert torch.isfinite(res).all() and (res != 0).any(), "the chain diverged"
+        out[name] = dict(ms_per_step=ms, value=B / ms * 1e3, unit="chain-steps/s")
+        del res
+    out["config"] = dict(chains=B, steps=steps, algo="langevin", prior_solver="gaussian",
+                         note="sample_torch_noise: torch.randn_like per step (the reference's draw), handed to the step "
+                              "kernel, which applies the update in its inverse column phase (langevin_step(eps=...)); "
+                              "optimize: update inside the kernel (descent_step)")
     return out
 
 
@@ -523,6 +577,8 @@ def main():
             # on 8 GPUs is 32 / 8 = 4 chains per GPU (frames shared between workgroups there)
             del x
             out["small_batches"] = {"B%d" % b: small_batch_line_mri(op, y, dev, b) for b in (4, 1)}
+            torch.cuda.empty_cache()
+            out["sampler_loop"] = sampler_lines_mri(op, y, dev, B)
         if world == 1 and not a.no_cpu_baseline:
             if a.task == "blackhole":
                 out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)
