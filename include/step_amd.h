@@ -490,6 +490,13 @@ int nufft_crop_apod(const float* grid_c64, int nframes, int T, const nufft_plan_
  *   nufft_inv_grid == an unnormalised inverse FFT2 of the grid + nufft_crop_apod.
  * work_c64: caller-owned scratch of nframes * R * G complex64 (any contents). */
 int nufft_grid_fft_supported(int R, int G);
+/* FFT2 of the oversampled grids at any size G <= 1024, in place (round 3; csrc/nufft_any.hip): the transform
+ * between nufft_pad_apod and nufft_interp, and between nufft_spread and nufft_crop_apod, for resolutions other
+ * than the fused transforms' (nufft_grid_fft_supported); mixed-radix passes over LDS, rows then column strips.
+ * grid_c64: [nframes][G][G] complex64; sign -1 forward (torch.fft.fft2), +1 unnormalised inverse.
+ * NO REFERENCE COUNTERPART (as the whole gridding path). */
+int nufft_fft2_any_supported(int G);
+int nufft_fft2_any(float* grid_c64, int nframes, int G, int sign, void* stream);
 int nufft_fwd_grid(const float* x, int nframes, int T, const nufft_plan_t* plan, float* work_c64,
                    float* grid_c64, void* stream);
 int nufft_inv_grid(const float* grid_c64, int nframes, int T, const nufft_plan_t* plan,

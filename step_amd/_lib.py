@@ -122,6 +122,8 @@ SIGNATURES = {
     "nufft_interp": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     "nufft_spread": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_p]),
     "nufft_crop_apod": (c_i, [c_p, c_i, c_i, C.POINTER(nufft_plan_t), c_p, c_f, c_p, c_p]),
+    "nufft_fft2_any_supported": (c_i, [c_i]),
+    "nufft_fft2_any": (c_i, [c_p, c_i, c_i, c_i, c_p]),
     "nufft_grid_fft_supported": (c_i, [c_i, c_i]),
     "nufft_interp_parts": (c_i, [C.POINTER(nufft_plan_t)]),
     "nufft_adjoint_supported": (c_i, [C.POINTER(nufft_plan_t), c_i]),

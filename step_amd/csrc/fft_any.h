@@ -120,6 +120,7 @@ FFT_HD void fft_any_butterfly(cf32 (&u)[R], const cf32* tw, int nb) {
     } else if constexpr (R == 3) {
         fft3<SIGN>(u[0], u[1], u[2]);
     } else {                                          // 5, 7: the direct sum, roots from the table
+        static_assert(R == 5 || R == 7, "no register butterfly of this radix");
         cf32 o[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -160,9 +161,9 @@ FFT_HD void fft_any_scatter(cf32* buf, const cf32* tw, int N, int s, unsigned ma
     for (int i = 0; i < MAXB; ++i, t += tpr) {
         if (t < nb && c < nl) {
             const int p = (int)(((unsigned)t * magic) >> 21), q = t - p * s;
-            fft_any_butterfly<SIGN, R>(v[i], tw, nb);
             cf32* out = buf + (q + R * s * p) * LD + c;
             const int w1 = p * s;                     // w_n^p = tw[p s]
+            fft_any_butterfly<SIGN, R>(v[i], tw, nb);
             out[0] = v[i][0];
 #pragma unroll
             for (int j = 1; j < R; ++j) {

@@ -14,60 +14,7 @@
 // Bound: the strips make 64..256-byte segments and the kept rows cross L2/HBM twice -- a general path, measured
 // at 192 x 192 against the tuned kernels in DESIGN.md; results agree with them to fp32 rounding.
 #include "common.h"
-#include "fft_any.h"
-
-#define ANY_THREADS 512
-#define ANY_LDS_BUF (64 * 1024)       // line buffer(s) of a workgroup: two workgroups per CU, three below 52 KB
-
-static size_t any_lds_bytes(int n, int ld, int nl, int direct) {
-    return ((size_t)n + (size_t)(direct ? 2 : 1) * n * ld + nl) * sizeof(cf32) + 16 * sizeof(float);
-}
-
-__device__ __forceinline__ void any_twiddles(cf32* tw, int n) {
-    for (int e = threadIdx.x; e < n; e += ANY_THREADS) {
-        float sn, cn;
-        sincospif((float)(2 * e) / (float)n, &sn, &cn);
-        tw[e] = c_make(cn, sn);
-    }
-}
-
-template <int SIGN, int R>
-__device__ __forceinline__ void any_pass_reg(cf32* buf, const cf32* tw, int n, int s, unsigned magic, int nl,
-                                             int nlp, int ld) {
-    constexpr int MAXB = FFT_ANY_REGS / R;
-    cf32 v[MAXB][R];
-    fft_any_gather<R, MAXB>(buf, n, nl, nlp, ld, (int)threadIdx.x, ANY_THREADS, v);
-    __syncthreads();
-    fft_any_scatter<SIGN, R, MAXB>(buf, tw, n, s, magic, nl, nlp, ld, (int)threadIdx.x, ANY_THREADS, v);
-    __syncthreads();
-}
-
-// transform of the nl lines of `a` in place; `b` (a second buffer) only when the plan has a direct pass
-template <int SIGN>
-__device__ __forceinline__ void any_fft(cf32* a, cf32* b, const cf32* tw, int n, int nl, int nlp, int ld,
-                                        const FftAnyPlan& plan) {
-    int s = 1;
-    for (int i = 0; i < plan.npass; ++i) {
-        const int r = plan.radix[i];
-        const unsigned mg = plan.magic[i];
-        switch (r) {
-        case 16: any_pass_reg<SIGN, 16>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 12: any_pass_reg<SIGN, 12>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 8: any_pass_reg<SIGN, 8>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 4: any_pass_reg<SIGN, 4>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 2: any_pass_reg<SIGN, 2>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 3: any_pass_reg<SIGN, 3>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 5: any_pass_reg<SIGN, 5>(a, tw, n, s, mg, nl, nlp, ld); break;
-        case 7: any_pass_reg<SIGN, 7>(a, tw, n, s, mg, nl, nlp, ld); break;
-        default:
-            fft_any_pass<SIGN>(a, b, tw, n, s, r, nl, ld, (int)threadIdx.x, ANY_THREADS);
-            __syncthreads();
-            for (int e = threadIdx.x; e < n * ld; e += ANY_THREADS) a[e] = b[e];
-            __syncthreads();
-        }
-        s *= r;
-    }
-}
+#include "fft_any_lds.h"
 
 // index into an n-entry twiddle table of the fftshift phase of spectrum line k: (n/2) k mod n
 __device__ __forceinline__ int any_shift_idx(int k, int n) {

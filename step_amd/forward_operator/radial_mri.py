@@ -16,8 +16,9 @@ Hand-written: the interpolation (+ residual + loss; grid tiles through LDS), the
 deterministic gather over host-binned tiles; from 16 chains on with a lane per chain) and, for
 R = 192, the oversampled-grid transforms themselves (nufft_fft.hip: 384-point passes fused with
 pad / crop / de-apodisation and pruned to the rows that are not zero), the forward column pass
-interpolating straight from its LDS strip (``fwd_interp = 'grid'`` forces the grid route).  Other sizes: pad and crop kernels around hipFFT through
-``torch.fft`` on the same stream (``grid_fft = 'library'`` forces that route)."""
+interpolating straight from its LDS strip (``fwd_interp = 'grid'`` forces the grid route).  Other sizes (grids up to 1024): pad and crop kernels
+around the library's own any-size FFT2 (nufft_any.hip, mixed-radix passes over LDS); ``grid_fft = 'library'`` puts
+hipFFT (``torch.fft`` on the same stream) there instead."""
 import ctypes as C
 import math
 
@@ -227,7 +228,7 @@ class RadialMRI(Operator):
         self._host = kb_plan(kappa, resolution, kernel_width)
         self.J = self._host["J"]
         self.max_chunk = max_chunk        # chains per pass: the oversampled grids are 8 G^2 bytes per frame
-        self.grid_fft = 'auto'            # 'auto' | 'fused' (nufft_fft.hip) | 'library' (torch.fft around pad / crop)
+        self.grid_fft = 'auto'            # 'auto' | 'fused' (nufft_fft.hip, R = 192) | 'generic' (nufft_any.hip) | 'library' (torch.fft)
         self.adjoint = 'auto'             # 'auto' | 'full' (nufft_spread + nufft_inv_grid over the whole grid)
         self.fwd_interp = 'auto'          # 'auto' | 'fused' (column pass + interpolation in one kernel, no grid) | 'grid'
         self._dev = {}
@@ -258,6 +259,12 @@ class RadialMRI(Operator):
         pad / crop kernels around a library FFT2."""
         return self.grid_fft == 'fused' or (self.grid_fft == 'auto'
                                             and bool(_lib.lib().nufft_grid_fft_supported(self.resolution, 2 * self.resolution)))
+
+    def _any_fft(self):
+        """The library's own FFT2 at any grid size up to 1024 (nufft_fft2_any: mixed-radix passes over LDS) for
+        the resolutions the fused transforms are not built for; ``grid_fft = 'library'`` forces torch.fft."""
+        return (not self._own_fft() and self.grid_fft in ('auto', 'generic')
+                and bool(_lib.lib().nufft_fft2_any_supported(2 * self.resolution)))
 
     def _fused_fwd(self, device):
         """nufft_fwd_interp (nufft_fft.hip): the forward column pass interpolates from its own LDS strip;
@@ -303,6 +310,9 @@ class RadialMRI(Operator):
         rc = _lib.lib().nufft_pad_apod(x.data_ptr(), B * T, T, C.byref(self._plan(x.device)), grid.data_ptr(),
                                        _lib.stream_of(x))
         _lib.check(rc, "nufft_pad_apod")
+        if self._any_fft():
+            _lib.check(_lib.lib().nufft_fft2_any(grid.data_ptr(), B * T, G, -1, _lib.stream_of(x)), "nufft_fft2_any")
+            return grid
         return torch.fft.fft2(grid)
 
     def _type2(self, x):
@@ -341,7 +351,11 @@ class RadialMRI(Operator):
                 _lib.check(L.nufft_inv_grid(grid.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
                                             work.data_ptr(), out[i:i + n].data_ptr(), st), "nufft_inv_grid")
                 continue
-            Z = torch.fft.ifft2(grid, norm="forward")               # unnormalised inverse (in place measured slower)
+            if self._any_fft():
+                _lib.check(L.nufft_fft2_any(grid.data_ptr(), n * T, G, 1, st), "nufft_fft2_any")
+                Z = grid
+            else:
+                Z = torch.fft.ifft2(grid, norm="forward")           # unnormalised inverse (in place measured slower)
             _lib.check(L.nufft_crop_apod(Z.data_ptr(), n * T, T, C.byref(plan), _lib.ptr(cs), out_scale,
                                          out[i:i + n].data_ptr(), st), "nufft_crop_apod")
         return out

@@ -87,7 +87,7 @@ def any_binary(tmp_path_factory):
     return str(exe)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 24, 30, 32, 48, 49, 64, 72, 96, 97, 128, 144, 160, 192, 200, 210, 256, 320, 384,
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 12, 16, 24, 30, 32, 48, 49, 64, 72, 96, 97, 128, 144, 160, 176, 192, 200, 208, 210, 256, 320, 384,
                                486, 512, 1000, 1024])
 def test_any_length_matches_numpy(any_binary, n):
     rng = np.random.RandomState(n)

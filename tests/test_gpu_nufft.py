@@ -131,16 +131,21 @@ def test_tiled_interpolation_equals_the_gathering_kernel(shared, dev):
     assert_close(a.loss(x, yb), b.loss(x, yb), 1e-6, "per-chain loss, per-chain measurement")
 
 
-@pytest.mark.parametrize("R", [64, 80])
-def test_other_resolutions_take_the_library_transform(R, dev):
-    """R != 192: pad / crop kernels around the library FFT2 (no own grid transforms); G = 128 has
-    whole 32 x 32 tiles (interpolation out of LDS), G = 160 has too (G % 32 == 0) -- both against
-    the direct NUDFT."""
+@pytest.mark.parametrize("route", ["generic", "library"])
+@pytest.mark.parametrize("R", [64, 80, 104, 256])
+def test_other_resolutions(R, route, dev):
+    """R != 192: pad / crop kernels around the library's own any-size FFT2 (nufft_fft2_any, mixed-radix passes
+    over LDS: the default) or around torch.fft (forced); G = 128 / 160 / 512 have whole 32 x 32 tiles
+    (interpolation out of LDS), G = 208 = 16 x 13 has not and takes a direct 13-point pass -- all against the
+    direct NUDFT."""
     from step_amd.forward_operator import golden_angle_radial
     frames = 3
     traj = golden_angle_radial(frames, 9, R)
     op, orc = make(spokes=9, frames=frames, resolution=R, trajectory=traj), NUDFTOracle(traj, R)
-    assert not op._own_fft()
+    assert not op._own_fft() and op._any_fft()
+    if route == "library":
+        op.grid_fft = "library"
+        assert not op._any_fft()
     gen = torch.Generator().manual_seed(R)
     x = torch.randn(2, frames, 2, R, R, generator=gen)
     y = orc(torch.randn(1, frames, 2, R, R, generator=gen)).float()
@@ -157,6 +162,23 @@ def test_other_resolutions_take_the_library_transform(R, dev):
     op.grid_fft = "fused"
     with pytest.raises(RuntimeError, match="built for R = 192"):
         op.gradient(x.to(dev), y.to(dev))
+
+
+@pytest.mark.parametrize("G", [2, 24, 128, 160, 194, 200, 384, 486, 512, 1024])
+def test_any_size_grid_fft2_against_the_library(G, dev):
+    """nufft_fft2_any through the C ABI: in place, both signs, against torch.fft on the same grids."""
+    from step_amd import _lib
+    L = _lib.lib()
+    assert L.nufft_fft2_any_supported(G) and not L.nufft_fft2_any_supported(1025) and not L.nufft_fft2_any_supported(1)
+    gen = torch.Generator(device=dev).manual_seed(G)
+    z = torch.randn(3, G, G, 2, device=dev, generator=gen)
+    zc = torch.view_as_complex(z.clone())
+    for sign, want in ((-1, torch.fft.fft2(zc)), (1, torch.fft.ifft2(zc, norm="forward"))):
+        w = z.clone()
+        _lib.check(L.nufft_fft2_any(w.data_ptr(), 3, G, sign, _lib.stream_of(w)), "nufft_fft2_any")
+        assert_close(w, torch.view_as_real(want), 2e-6, "sign %d" % sign)
+    assert L.nufft_fft2_any(z.data_ptr(), 3, G, 0, _lib.stream_of(z)) != 0
+    assert L.nufft_fft2_any(z.data_ptr(), 3, 2048, -1, _lib.stream_of(z)) != 0
 
 
 @pytest.mark.parametrize("shared", [False, True])
