@@ -63,6 +63,9 @@ class bh_update_t(C.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol include/step_amd.h declares
+# the version of include/step_amd.h these signatures were written against (step_abi_version(); checked at load)
+ABI_VERSION = 12
+
 SIGNATURES = {
     "step_last_error": (C.c_char_p, []),
     "step_abi_version": (c_i, []),
@@ -154,6 +157,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
+        got = L.step_abi_version()
+        if got != ABI_VERSION:             # a stale .so under newer bindings (or the reverse) would misread arguments
+            raise RuntimeError("step_amd: %s speaks ABI %d, these bindings %d -- rebuild with `make -C step_amd/csrc`"
+                               % (LIB_PATH, got, ABI_VERSION))
         _lib = L
     return _lib
 

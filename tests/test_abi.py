@@ -76,7 +76,7 @@ int main(void) {
 def test_binding_covers_header_exactly():
     from step_amd import _lib
     assert set(_lib.SIGNATURES) == set(header_functions())
-    assert _lib.lib().step_abi_version() == 12
+    assert _lib.lib().step_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_host_entry_points_reject_bad_arguments():
@@ -119,3 +119,9 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libstep_amd.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build(): make (a no-op when the tree is built) + load + the ABI version of the bindings."""
+    import __graft_entry__ as g
+    g.build()
