@@ -47,7 +47,11 @@
 // pipeline stage run one after the other instead of interleaved, which is what keeps their
 // temporaries (and with them the kernel) within the register file.
 #define LG2_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a group of `n` instructions of the classes in `mask` (0x002 vector ALU, 0x020 vector memory read) at this
+// point of the scheduling region's order: alternating groups spread loads between arithmetic
+#define LG2_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #else
+#define LG2_SGB(mask, n)
 #define LG2_FENCE()
 #define LG2_DEV inline
 #define LG2_OPAQUE(v) asm volatile("" : "+r"(v))
@@ -104,6 +108,12 @@ LG2_DEV void lg2_load_strip(const float* xr, const float* xi, unsigned off, cf32
     }
 }
 
+// one of the 16 (re, im) pairs of lg2_load_strip
+LG2_DEV void lg2_load_pair(const float* xr, const float* xi, unsigned off, int a, cf32 (&v)[16]) {
+    const unsigned o = off + (unsigned)a * (12u * LG2_R * 4u);
+    v[a] = c_make(lg2_ld(xr, o), lg2_ld(xi, o));
+}
+
 // Tables of one mask frame.  The caller syncs before (LDS reuse) -- this function ends synced.
 // `my_row` = rowlist[tid] for tid < nk (nk <= LG2_NKC_MAX <= LG2_THREADS), fetched by the caller
 // ahead of the first strip: fetched here, behind the strip's 32 loads, the wait for it would be
@@ -149,11 +159,18 @@ LG2_DEV float lg2_block_sum(const Ctx& ctx, float v, float* red) {
 // rowlist: the kept rows of this mask frame (global memory); rowl: the same list in LDS.
 // Row j of round r is handled by lanes 16 j .. 16 j + 15 of thread index e = tid + r NT; 2 NT / 16
 // must cover nk.  Ends with the row buffer complete but NOT synced when with_grad is false.
-template <int NT, class Ctx>
+// `hook(i)`, i = 0, 1, 2: called once after the first round's measurement loads are out, once between the two
+// pass-B rounds and once after them -- the persistent kernel requests the three strips of its next frame
+// there, one at a time, so that no wave ever has more loads in flight than the counter holds (63).
+struct Lg2NoHook {
+    LG2_DEV void operator()(int) const {}
+};
+
+template <int NT, class Ctx, class Hook = Lg2NoHook>
 LG2_DEV void lg2_row_phase(const Ctx& ctx, cf32* Rk, const cf32* tw, const int* rowl,
                            const int* __restrict__ rowlist, int nk, const float* __restrict__ yr,
                            const float* __restrict__ yi, float cs2, bool with_grad, int frame,
-                           float& acc) {
+                           float& acc, const Hook& hook = Hook()) {
     constexpr int R = LG2_R, RS = LG2_RS;
     // measurement rows of this thread's pass-B tasks (row j, group c): kx = c + 16 d; the
     // first round's are fetched here, the second round's under the first round's transform
@@ -170,6 +187,7 @@ LG2_DEV void lg2_row_phase(const Ctx& ctx, cf32* Rk, const cf32* tw, const int* 
         }                                                                          \
     }
     LG2_YLOAD(j0, ya, yb)
+    hook(0);
     ctx.sync();                                  // Rk complete
     ctx.tick(2, frame);
 
@@ -216,7 +234,11 @@ LG2_DEV void lg2_row_phase(const Ctx& ctx, cf32* Rk, const cf32* tw, const int* 
     LG2_FENCE();
     LG2_ROW_B(j0, ya, yb)
     LG2_FENCE();
+    hook(1);
+    LG2_FENCE();
     LG2_ROW_B(j1, yc, yd)
+    LG2_FENCE();
+    hook(2);
 #undef LG2_ROW_B
 #undef LG2_YLOAD
     if (with_grad) {

@@ -94,7 +94,7 @@ LG2_DEV void lg2p_body(const Ctx& ctx, const float* __restrict__ x, const float*
         }
         // one stage: pass B of strip s - 1 (from u), pass A of strip s (register set `cur`), the
         // A -> B exchange through the strip buffer, then `cur` is refilled with strip s + NSETS
-#define LG2_FWD_STAGE(s, cur)                                                          \
+#define LG2_FWD_STAGE(s, cur, prev)                                                          \
         {                                                                              \
             if (YQ) {                                                                  \
                 /* masked-out rows 32 s .. 32 s + 31 of the measurement (both planes), fetched a */ \
@@ -115,9 +115,20 @@ LG2_DEV void lg2p_body(const Ctx& ctx, const float* __restrict__ x, const float*
                 const int n = lg2_phys(((s) - 1) * SW + col);                          \
                 unsigned rq[3] = {rpB[0], rpB[1], rpB[2]};                             \
                 LG2_OPAQUE(rq[0]); LG2_OPAQUE(rq[1]); LG2_OPAQUE(rq[2]);               \
+                /* strip s + 2 goes into the set that stage s - 1 has just handed to the strip buffer, */ \
+                /* requested HERE, a few loads behind each of pass B's stores, not as a burst of 32 */     \
+                /* (which holds every wave at the issue until the address unit has worked it off) */       \
+                const bool refill = (s) + 2 < NS && !YQ;                               \
+                unsigned o = offA + (unsigned)((s) + 2) * (SW * 4u);                   \
+                LG2_OPAQUE(o);                                                         \
                 _Pragma("unroll") for (int d = 0; d < 12; ++d) {                       \
                     const int j = LG2_RP(rq, d);                                       \
                     if (j >= 0) L.Rk[j * RS + n] = c_make(sgB * u[d].x, sgB * u[d].y); \
+                    if (refill) {                                                      \
+                        lg2_load_pair(xr, xi, o, d, prev);                             \
+                        if (d < 4) lg2_load_pair(xr, xi, o, 12 + d, prev);             \
+                        LG2_FENCE();                                                   \
+                    }                                                                  \
                 }                                                                      \
             }                                                                          \
             LG2_FENCE();                                                               \
@@ -132,7 +143,7 @@ LG2_DEV void lg2p_body(const Ctx& ctx, const float* __restrict__ x, const float*
             if (a_task) {                                                              \
                 _Pragma("unroll") for (int c = 0; c < 16; ++c) L.S[(12 * c + bb) * SW + col] = cur[c]; \
             }                                                                          \
-            if ((s) + NSETS < NS && (!YQ || a_task)) {                                 \
+            if ((s) + NSETS < NS && YQ && a_task) {                                    \
                 unsigned o = offA + (unsigned)((s) + NSETS) * (SW * 4u);               \
                 LG2_OPAQUE(o);                                                         \
                 lg2_load_strip(xr, xi, o, cur);                                        \
@@ -148,12 +159,12 @@ LG2_DEV void lg2p_body(const Ctx& ctx, const float* __restrict__ x, const float*
         if (YQ) {
 #pragma unroll 1
             for (int s = 0; s < NS; s += 2) {
-                LG2_FWD_STAGE(s, a0)
-                LG2_FWD_STAGE(s + 1, a1)
+                LG2_FWD_STAGE(s, a0, a1)
+                LG2_FWD_STAGE(s + 1, a1, a0)
             }
         } else {
-            LG2_FWD_STAGE(0, a0) LG2_FWD_STAGE(1, a1) LG2_FWD_STAGE(2, a2)
-            LG2_FWD_STAGE(3, a0) LG2_FWD_STAGE(4, a1) LG2_FWD_STAGE(5, a2)
+            LG2_FWD_STAGE(0, a0, a2) LG2_FWD_STAGE(1, a1, a0) LG2_FWD_STAGE(2, a2, a1)
+            LG2_FWD_STAGE(3, a0, a2) LG2_FWD_STAGE(4, a1, a0) LG2_FWD_STAGE(5, a2, a1)
         }
 #undef LG2_FWD_STAGE
         ctx.tick(1, frame);
@@ -196,16 +207,20 @@ LG2_DEV void lg2p_body(const Ctx& ctx, const float* __restrict__ x, const float*
             }
         }
         // the three register sets are free: the next frame's first strips travel under the row
-        // phase and the inverse column phase
-        if (has_next) {
+        // phase and the inverse column phase.  Requested one strip at a time from inside the row phase
+        // (behind its measurement loads, between its rounds): all 96 loads at once ran every wave into
+        // the 63-load limit of the counter, and the whole workgroup stood at the issue for the 5 us
+        // the first of them took to come back -- before a single row had been touched.
+        const float* xf = x + (size_t)(has_next ? fnext : frame) * fsz;
+        auto next_strips = [&](int i) {
+            if (!has_next) return;                       // uniform
             LG2_IDS(tn)
-            const float* xf = x + (size_t)fnext * fsz;
-            lg2_load_strip(xf, xf + R * R, offA, a0);
-            lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
-            lg2_load_strip(xf, xf + R * R, offA + 2 * SW * 4u, a2);
-        }
+            if (i == 0) lg2_load_strip(xf, xf + R * R, offA, a0);
+            else if (i == 1) lg2_load_strip(xf, xf + R * R, offA + SW * 4u, a1);
+            else lg2_load_strip(xf, xf + R * R, offA + 2 * SW * 4u, a2);
+        };
         lg2_row_phase<LG2_THREADS>(ctx, L.Rk, L.tw, L.rowl, rows + (size_t)mf * R, nk, yr, yi, cs2,
-                                   grad != nullptr, frame, acc);
+                                   grad != nullptr, frame, acc, next_strips);
         if (grad) {
             ctx.sync();
             ctx.tick(5, frame);
