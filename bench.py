@@ -62,6 +62,11 @@ def parse():
                         "(profiles/r03_torchrun_vs_bare.txt): both within 1 %% of the bare run -- each rank's clock "
                         "stops BEFORE the closing barrier either way -- so the default is the one that needs no "
                         "second rendezvous")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="N > 1 ranks on ONE card (rank r takes cuda:(r %% visible devices)) with the process group on "
+                        "gloo instead of RCCL (which refuses two ranks on a device): the whole torch.distributed.run "
+                        "path -- rendezvous, per-rank operators, barriers, MAX, gather, the one JSON line -- except RCCL "
+                        "itself; the line says so and is not a scaling measurement")
     p.add_argument("--no-small-batches", action="store_true",
                    help="skip the extra B = 8 / B = 1 and sampler-loop measurements of the default blackhole run")
     return p.parse_args()
@@ -381,8 +386,13 @@ def main():
     dist = side = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if a.barrier == "gloo":
+        if a.rehearse_on_one_gpu:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
+            local = local % max(1, torch.cuda.device_count())
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.barrier == "gloo" and not a.rehearse_on_one_gpu:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the ranks meet on the loopback
             try:
                 side = dist.new_group(backend="gloo")
@@ -425,7 +435,7 @@ def main():
         x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
         y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
 
-    comm = Comm(dist, side, dev, world)
+    comm = Comm(dist, side, torch.device("cpu") if a.rehearse_on_one_gpu else dev, world)
 
     def barrier():
         if dist is not None:
@@ -552,7 +562,8 @@ def main():
                    prewarm_ms=prewarm_ms, prewarm_steps=prewarm_steps,
                    per_rank_ms_per_step=[1e3 * v / a.steps for v in per_rank],
                    bracket_barrier=("none (one process)" if dist is None else
-                                    "gloo (host)" if side is not None else "rccl"),
+                                    "gloo (rehearsal: all ranks on one card, NOT a scaling measurement)"
+                                    if a.rehearse_on_one_gpu else "gloo (host)" if side is not None else "rccl"),
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -34,3 +36,26 @@ def test_gpus_1_stays_in_process():
     r = _run(["--gpus", "1", "--dry-run"])
     assert r["n_gpus"] == 1 and r["max_over_ranks"] == 1.0
     assert len(r["per_rank_ms_per_step"]) == 1 and r["ms_per_step"] == r["per_rank_ms_per_step"][0]
+
+
+@pytest.mark.gpu
+def test_two_ranks_under_torch_distributed_run_on_one_card():
+    """The driver's N > 1 launch line on a one-GPU box: `--rehearse-on-one-gpu` puts both ranks on cuda:0 with
+    the process group on gloo (RCCL refuses two ranks on a device) -- rendezvous, per-rank operators, bracket
+    barriers, MAX over ranks, per-rank times, ONE JSON line from rank 0.  Not a scaling measurement."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "10", "--warmup", "3", "--batch", "8", "--rehearse-on-one-gpu"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and len(d["per_rank_ms_per_step"]) == 2
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) < 1e-9
+    assert abs(d["value"] - 2 * 8 * 10 / (d["ms_per_step"] * 10 * 1e-3)) < 1e-3 * d["value"]
+    assert "rehearsal" in d["bracket_barrier"] and d["scaling"] == "weak"
