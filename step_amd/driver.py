@@ -20,12 +20,19 @@ __all__ = ["init_distributed", "shard_items", "chain_generator", "gather_to_rank
            "sample_posterior", "write_sample_dir"]
 
 
-def init_distributed(backend=None):
-    """One process per GPU (torchrun env).  Returns (rank, world, device)."""
+def init_distributed(backend=None, rehearse_on_one_gpu=False):
+    """One process per GPU (torchrun env).  Returns (rank, world, device).
+    ``rehearse_on_one_gpu``: every rank takes cuda:(LOCAL_RANK % visible devices) and the process group runs on
+    gloo (RCCL refuses two ranks on a device) -- the sharded path on a one-GPU box, RCCL itself excepted."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cuda = torch.cuda.is_available()
+    if rehearse_on_one_gpu:
+        backend = "gloo"
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if cuda:
+            local = local % max(1, torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend or ("nccl" if cuda else "gloo"))
     if cuda:
@@ -55,7 +62,10 @@ def gather_to_rank0(local, ids, n_items, group=None):
         return out
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n_max = (n_items + world - 1) // world
-    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # a gloo group gathers host tensors only: device results cross it through the host (rehearsal, CPU tests)
+    via_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    wire = torch.device("cpu") if via_host else local.device
+    pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=wire)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, bufs, dst=0, group=group)
@@ -64,7 +74,7 @@ def gather_to_rank0(local, ids, n_items, group=None):
     out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):
         rid = shard_items(n_items, r, world)
-        out[torch.as_tensor(rid, dtype=torch.long, device=local.device)] = bufs[r][: len(rid)]
+        out[torch.as_tensor(rid, dtype=torch.long, device=local.device)] = bufs[r][: len(rid)].to(local.device)
     return out
 
 
@@ -99,7 +109,8 @@ def sample_posterior(sampler, model, operator, measurement, num_samples, seed=37
                 int(seed) + 100003 * (item_offset + chunk[0] + 1))
         z_start = z * sampler.annealing_scheduler.sigma_max
         kw = dict(gt=gt) if gt is not None else {}
-        outs.append(sampler.sample(model, z_start, operator, measurement, evaluator=evaluator, **kw))
+        # detached: the final decode of a prior with trainable weights would otherwise hand on its autograd graph
+        outs.append(sampler.sample(model, z_start, operator, measurement, evaluator=evaluator, **kw).detach())
         if hasattr(sampler, "set_chains"):
             sampler.set_chains(None, None)
     if outs:
@@ -126,4 +137,4 @@ def write_sample_dir(idx_dir, observations, samples, videos=None):
     if videos is not None:
         torch.save(videos.to("cpu"), idx_dir / "videos.pth")
     for i in range(samples.shape[0]):
-        torch.save(samples[i:i + 1].to("cpu").clone(), idx_dir / ("sample_%d.pth" % i))
+        torch.save(samples[i:i + 1].detach().to("cpu").clone(), idx_dir / ("sample_%d.pth" % i))

@@ -144,9 +144,11 @@ def main(argv=None):
     p.add_argument("--pixel-space", action="store_true", help="latent_wrapper=False (optimize() on decoded frames)")
     p.add_argument("--noise", default="philox", choices=["philox", "torch"])
     p.add_argument("--prior-solver", default=None, help="override mcmc prior_solver (e.g. gaussian)")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="under torchrun on a one-GPU box: all ranks on one card, process group on gloo")
     a = p.parse_args(argv)
 
-    rank, world, device = driver.init_distributed()
+    rank, world, device = driver.init_distributed(rehearse_on_one_gpu=a.rehearse_on_one_gpu)
     cfg = load_task(a.task, a.config)
     sc = cfg["sampler"]
     if a.annealing_steps:
