@@ -106,3 +106,42 @@ def test_any_length_matches_numpy(any_binary, n):
 def test_plan_refuses_what_it_cannot_hold(any_binary):
     r = subprocess.run([any_binary, "1025", "1", "1", "-1", "1"], input=b"", stdout=subprocess.PIPE)
     assert r.returncode == 2
+
+
+PLAN_SRC = r"""
+#include <cstdio>
+#include "fft_any.h"
+// every length 2 .. 1024: a plan exists, its radices multiply to N, and the kernels' line counts (512 threads,
+// 64 KB of line buffers, with and without the padded stride) are positive with everything inside 160 KB of LDS
+int main() {
+    int bad = 0;
+    for (int n = 2; n <= FFT_ANY_MAX_N; ++n) {
+        FftAnyPlan p;
+        if (!fft_any_plan(n, &p)) { printf("no plan %d\n", n); ++bad; continue; }
+        long prod = 1;
+        for (int i = 0; i < p.npass; ++i) prod *= p.radix[i];
+        if (prod != n) { printf("radices of %d multiply to %ld\n", n, prod); ++bad; }
+        for (int pad = 0; pad < 2; ++pad) {
+            const int nl = fft_any_lines(n, &p, 512, pad, 64 * 1024);
+            const size_t lds = ((size_t)n + (size_t)(p.direct ? 2 : 1) * n * (nl + pad) + nl) * sizeof(cf32) + 64;
+            if (nl < 1 || lds > 160 * 1024) { printf("n %d pad %d: %d lines, %zu bytes\n", n, pad, nl, lds); ++bad; }
+            for (int i = 0; i < p.npass; ++i)
+                if (fft_any_in_regs(p.radix[i]) && n / p.radix[i] > fft_any_maxb(p.radix[i]) * (512 / nl)) {
+                    printf("n %d radix %d does not fit the registers at %d lines\n", n, p.radix[i], nl); ++bad;
+                }
+        }
+    }
+    printf("bad %d\n", bad);
+    return bad != 0;
+}
+"""
+
+
+def test_every_length_has_a_plan_that_fits(tmp_path):
+    src = tmp_path / "plan.cpp"
+    src.write_text(PLAN_SRC)
+    exe = tmp_path / "plan"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "step_amd", "csrc"), str(src), "-o", str(exe)],
+                   check=True)
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("bad 0"), r.stdout[-2000:]

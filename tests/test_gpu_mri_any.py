@@ -156,3 +156,19 @@ def test_refusals(dev):
     from step_amd.forward_operator import get_operator
     with pytest.raises(ValueError, match="192 only"):
         get_operator("mri_multicoil", acc_factor=4, resolution=64, frames=5, coils=2)
+
+
+@pytest.mark.parametrize("res", [1021, 1023, 998, 6, 3])
+def test_awkward_sizes(res, dev):
+    """A prime near the limit (one direct pass and a second buffer, few lines per workgroup), 3 x 11 x 31,
+    2 x 499, and frames smaller than a strip."""
+    frames = 1 if res > 100 else 3
+    op, orc = make(res, "same_mask", 4, min(8, res // 2), frames)
+    gen = torch.Generator().manual_seed(res)
+    x = torch.randn(2, frames, 2, res, res, generator=gen)
+    y = orc(torch.randn(1, frames, 2, res, res, generator=gen)) + 0.1 * torch.randn(1, frames, 2, res, res, generator=gen)
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
