@@ -332,13 +332,16 @@ class MultiCoilMRI(DynamicMRI):
     BASELINE.json's north_star names.  ``sens``: complex [C, R, R] (or real [C, 2, R, R]); ``coils``:
     build ``birdcage_maps(coils)`` instead.  ``__call__`` returns [B, T, C, 2, R, R]; ``loss`` /
     ``gradient`` keep the single-coil semantics summed over coils.  With C = 1 and S = 1 every
-    result equals the single-coil operator's first-generation kernels bit for bit."""
+    result equals the single-coil operator's first-generation kernels bit for bit.  Resolutions other
+    than 192 (the tuned kernels') run the coil multiply / combine kernels around the any-size
+    single-coil kernels (csrc/mri_any.hip) on B x (T C) frames."""
 
     def __init__(self, acc_factor, mode='same_mask', resolution=192, frames=12, num_acs_lines=12,
                  sigma=0, sens=None, coils=None):
         super().__init__(acc_factor, mode, resolution, frames, num_acs_lines, sigma)
-        if int(resolution) != 192:
-            raise ValueError("mri_multicoil: the coil kernels are built for resolution=192 only (got %r)" % (resolution,))
+        if (int(resolution) * int(resolution)) % 4:
+            raise ValueError("mri_multicoil: resolution %r (the coil multiply moves four pixels at a time: R * R must "
+                             "be a multiple of 4)" % (resolution,))
         if sens is None:
             if not coils:
                 raise ValueError("mri_multicoil needs `sens` ([C, R, R] complex) or `coils`")
@@ -358,10 +361,36 @@ class MultiCoilMRI(DynamicMRI):
             self._sens_dev[key] = self.sens.to(device)
         return self._sens_dev[key]
 
+    def _any_ws_mc(self, x):
+        """Workspace of the any-size kernels for the B x (T C) single-coil frames of the split path."""
+        B, T, R = x.shape[0], self.frames * self.coils, self.resolution
+        nb = _lib.lib().mri_any_ws_bytes(B, T, R, R, self._max_rows)
+        if nb == 0:
+            raise ValueError("mri_multicoil: frames of %d x %d are outside the kernels' range (2 .. 1024)" % (R, R))
+        key = ("any_ws_mc", str(x.device))
+        ws = self._dev_tables.get(key)
+        if ws is None or ws.numel() < nb:
+            ws = torch.empty(nb, device=x.device, dtype=torch.uint8)
+            self._dev_tables[key] = ws
+        return ws
+
     def _launch_forward(self, x):
         B, T = self._dims(x)
         rows, nrows = self._tables(x.device)
         out = torch.empty(B, T, self.coils, 2, self.resolution, self.resolution, device=x.device)
+        if int(self.resolution) != 192:
+            # other resolutions: coil multiply, then the any-size single-coil kernels on B x (T C) frames
+            L, st, Cn, R = _lib.lib(), _lib.stream_of(x), self.coils, self.resolution
+            rows, nrows = self._tables_mc(x.device)
+            z = torch.empty_like(out)
+            _lib.check(L.mri_coil_mul(x.data_ptr(), self._sens_on(x.device).data_ptr(), Cn, B * T, R, z.data_ptr(), st),
+                       "mri_coil_mul")
+            ws = self._any_ws_mc(x)
+            mf = self.mask.shape[1] * (Cn if self.mask.shape[1] > 1 else 1)
+            _lib.check(L.mri_forward_any(z.data_ptr(), B, T * Cn, R, R, rows.data_ptr(), nrows.data_ptr(), mf,
+                                         self._max_rows, ws.data_ptr(), ws.numel(), out.data_ptr(), st),
+                       "mri_forward_any (multi-coil)")
+            return out
         rc = _lib.lib().mri_forward_mc(x.data_ptr(), self._sens_on(x.device).data_ptr(), self.coils, B, T,
                                        self.resolution, rows.data_ptr(), nrows.data_ptr(),
                                        self.mask.shape[1], self._max_rows, out.data_ptr(), _lib.stream_of(x))
@@ -401,9 +430,15 @@ class MultiCoilMRI(DynamicMRI):
         loss = torch.empty(B + 1, device=dev, dtype=torch.float32)
         g = torch.empty_like(z) if need_grad else None
         mf = self.mask.shape[1] * (Cn if self.mask.shape[1] > 1 else 1)
-        rc = L.mri_loss_grad(z.data_ptr(), y.data_ptr(), y.shape[0], B, T * Cn, R, rows.data_ptr(),
-                             nrows.data_ptr(), mf, self._max_rows, _lib.ptr(chain_scale), self.kernel_variant,
-                             part.data_ptr(), loss.data_ptr(), loss.data_ptr() + 4 * B, _lib.ptr(g), st)
+        if int(R) != 192:
+            ws = self._any_ws_mc(x)
+            rc = L.mri_loss_grad_any(z.data_ptr(), y.data_ptr(), y.shape[0], B, T * Cn, R, R, rows.data_ptr(),
+                                     nrows.data_ptr(), mf, self._max_rows, _lib.ptr(chain_scale), ws.data_ptr(),
+                                     ws.numel(), loss.data_ptr(), loss.data_ptr() + 4 * B, _lib.ptr(g), st)
+        else:
+            rc = L.mri_loss_grad(z.data_ptr(), y.data_ptr(), y.shape[0], B, T * Cn, R, rows.data_ptr(),
+                                 nrows.data_ptr(), mf, self._max_rows, _lib.ptr(chain_scale), self.kernel_variant,
+                                 part.data_ptr(), loss.data_ptr(), loss.data_ptr() + 4 * B, _lib.ptr(g), st)
         _lib.check(rc, "mri_loss_grad (multi-coil, split)")
         grad = None
         if need_grad:
@@ -462,6 +497,10 @@ class MultiCoilMRI(DynamicMRI):
         # one kernel per frame for all coils pays once the frames alone fill most of the chip; below
         # that (scripts/kbench_mri_coils.py: 4 chains x 8 coils 0.34 ms fused, 0.14 ms split) the split
         # path's B x T x C single-coil frames spread over the idle CUs
+        if int(self.resolution) != 192:                  # coil multiply / any-size kernels / coil combine
+            if B * T > 65535:
+                raise ValueError("mri_multicoil at resolution %d: at most 65535 frames per call" % self.resolution)
+            return self._launch_split(x, y, need_grad, chain_scale)
         fused = (self.split_coils is None and self._max_rows <= 64 and (self.coils == 1 or B * T >= 144)) \
             if self.fused_coils is None else self.fused_coils
         if fused:

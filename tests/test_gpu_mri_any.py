@@ -153,9 +153,6 @@ def test_refusals(dev):
     assert rc != 0 and "workspace" in _lib.lib().step_last_error().decode()
     with pytest.raises(ValueError, match="expects"):
         op(torch.zeros(1, 5, 2, 32, 64, device=dev))          # the mask is 64 rows high
-    from step_amd.forward_operator import get_operator
-    with pytest.raises(ValueError, match="192 only"):
-        get_operator("mri_multicoil", acc_factor=4, resolution=64, frames=5, coils=2)
 
 
 @pytest.mark.parametrize("res", [1021, 1023, 998, 6, 3])

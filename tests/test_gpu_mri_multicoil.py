@@ -89,3 +89,32 @@ def test_matches_the_coil_by_coil_oracle(C, mode, acc, acs, split, dev):
     want = torch.autograd.grad((orc(xo) * gk).sum(), xo)[0]
     got = torch.autograd.grad((op(xr) * gk.to(dev)).sum(), xr)[0]
     assert_close(got, want, RTOL, "adjoint (vector-Jacobian product of A)")
+
+
+@pytest.mark.parametrize("R,C,mode,acc,acs,frames", [(128, 4, "same_mask", 4, 12, 3), (96, 3, "random_split_mask", 3, 6, 4),
+                                                     (200, 2, "split_mask", 5, 10, 2)])
+def test_other_resolutions_match_the_coil_by_coil_oracle(R, C, mode, acc, acs, frames, dev):
+    """Resolutions other than 192: coil multiply / combine around the any-size single-coil kernels."""
+    from step_amd.forward_operator import birdcage_maps, get_operator
+    sens = birdcage_maps(C, R) * torch.polar(torch.ones(C, 1, 1), torch.linspace(0, 2, C).view(C, 1, 1))
+    op = get_operator("mri_multicoil", mode=mode, acc_factor=acc, resolution=R, frames=frames, num_acs_lines=acs, sens=sens)
+    orc = MultiCoilMRIOracle(acc, mode, R, frames, acs, sens)
+    gen = torch.Generator().manual_seed(R + C)
+    x = torch.randn(2, frames, 2, R, R, generator=gen)
+    y = orc(torch.randn(2, frames, 2, R, R, generator=gen)) + 0.1 * torch.randn(2, frames, C, 2, R, R, generator=gen)
+    assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
+    g_ref, l_ref = orc.gradient(x, y, return_loss=True)
+    g_got, l_got = op.gradient(x.to(dev), y.to(dev), return_loss=True)
+    assert_close(l_got, l_ref, RTOL, "loss")
+    assert_close(g_got, g_ref, RTOL, "gradient")
+    assert_close(op.loss(x.to(dev), y.to(dev)), orc.loss(x, y), RTOL, "per-chain loss")
+    g1 = op.gradient(x.to(dev), y[:1].to(dev))
+    assert_close(g1[1], orc.gradient(x[1:], y[:1])[0], RTOL, "broadcast measurement")
+    xr = x.to(dev).clone().requires_grad_(True)
+    gk = torch.randn(2, frames, C, 2, R, R, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    want = torch.autograd.grad((orc(xo) * gk).sum(), xo)[0]
+    got = torch.autograd.grad((op(xr) * gk.to(dev)).sum(), xr)[0]
+    assert_close(got, want, RTOL, "adjoint (vector-Jacobian product of A)")
+    with pytest.raises(ValueError, match="multiple of 4"):
+        get_operator("mri_multicoil", acc_factor=2, resolution=75, frames=2, coils=2)
