@@ -29,7 +29,8 @@ def test_gpus_2_spawns_two_ranks():
     # in the line, the job's time is their MAX.  A dry-run step sleeps 1 ms on rank 0, 2 ms on rank 1
     per = r["per_rank_ms_per_step"]
     assert len(per) == 2 and r["ms_per_step"] == max(per)
-    assert 1.0 <= per[0] < 1.9 and 2.0 <= per[1] < 3.5
+    # lower bounds only: a sleep never returns early, but on a busy host it may return late by any amount
+    assert per[0] >= 1.0 and per[1] >= 2.0
 
 
 def test_gpus_1_stays_in_process():
