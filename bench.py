@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--task", default="blackhole", choices=["blackhole", "mri", "mri_radial"])
     p.add_argument("--coils", type=int, default=0,
                    help="--task mri: C > 0 runs the multi-coil operator (no reference counterpart)")
+    p.add_argument("--resolution", type=int, default=192,
+                   help="--task mri: frame size R x R (192 = the shipped configuration and the tuned kernels; any "
+                        "other size runs the any-size kernels, csrc/mri_any.hip)")
     p.add_argument("--batch", type=int, default=None, help="chains per GPU (default: blackhole 64, mri 256)")
     p.add_argument("--path", default="auto", choices=["auto", "sep3", "sep", "dense"])
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -423,17 +426,21 @@ def main():
                     "12x2x192x192, 32 golden-angle spokes x 192 per frame")
     else:
         from step_amd.forward_operator import get_operator
-        cfg = dict(acc_factor=6, mode="same_mask", resolution=192, frames=12, num_acs_lines=24)
+        R = a.resolution
+        cfg = dict(acc_factor=6, mode="same_mask", resolution=R, frames=12, num_acs_lines=R // 8)
         if a.coils > 0:
             op = get_operator("mri_multicoil", coils=a.coils, **cfg)
             B = a.batch or 64
             workload = "multi-coil mri operator (%d coils, no reference counterpart) loss fwd + adjoint, " \
-                       "12x2x192x192, acc 6 / 24 ACS same_mask" % a.coils
+                       "12x2x%dx%d, acc 6 / %d ACS same_mask" % (a.coils, R, R, R // 8)
         else:
             op = get_operator("mri", **cfg)
-            workload = "mri operator loss fwd + adjoint, 12x2x192x192, acc 6 / 24 ACS same_mask"
-        x = torch.randn(B, 12, 2, 192, 192, device=dev, generator=gen)
-        y = op(torch.randn(1, 12, 2, 192, 192, device=dev, generator=gen))
+            if R != 192:
+                B = a.batch or 64
+            workload = "mri operator loss fwd + adjoint, 12x2x%dx%d, acc 6 / %d ACS same_mask%s" % (
+                R, R, R // 8, "" if R == 192 else " (any-size kernels)")
+        x = torch.randn(B, 12, 2, R, R, device=dev, generator=gen)
+        y = op(torch.randn(1, 12, 2, R, R, device=dev, generator=gen))
 
     comm = Comm(dist, side, torch.device("cpu") if a.rehearse_on_one_gpu else dev, world)
 
@@ -532,7 +539,7 @@ def main():
                         kernels_ms=kern)
         elif a.coils > 0:
             ms = kern["mri_loss_grad_mc"]
-            byts = (16.0 + 8.0 * a.coils) * 12 * 192 * 192 * B       # read x, write grad, read y of C coils
+            byts = (16.0 + 8.0 * a.coils) * 12 * float(a.resolution) ** 2 * B    # read x, write grad, read y of C coils
             gbs = byts / (ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad_mc", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=gbs / HBM_PEAK_GBS, traffic=None,
@@ -543,14 +550,15 @@ def main():
             # exist are x read + gradient written per chain and y read once: 16*T*R*R*B + 8*T*R*R.
             # That is the primary fraction; SURVEY 8d's 24*T*R*R per chain (a measurement per chain)
             # over-counts y by B - 1 reads and is reported next to it.
-            exist = 16.0 * 12 * 192 * 192 * B + 8.0 * 12 * 192 * 192
-            survey = 24.0 * 12 * 192 * 192 * B
+            RR = float(a.resolution) ** 2
+            exist = 16.0 * 12 * RR * B + 8.0 * 12 * RR
+            survey = 24.0 * 12 * RR * B
             ms = kern["mri_loss_grad"]
             gbs = exist / (ms * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel="mri_loss_grad", achieved=gbs, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                        traffic=(measured_traffic("k_mri_loss_grad2p", B == 256)
-                                 or measured_traffic("k_mri_loss_grad2", B == 256)),
+                        traffic=(measured_traffic("k_mri_loss_grad2p", B == 256 and a.resolution == 192)
+                                 or measured_traffic("k_mri_loss_grad2", B == 256 and a.resolution == 192)),
                         algorithmic="(16*T*R*R per chain + 8*T*R*R once: one measurement for all chains) x %d chains" % B,
                         survey_8d_view=dict(achieved=survey / (ms * 1e-3) / 1e9, frac=survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                             algorithmic="24*T*R*R bytes per chain x %d chains (a measurement per chain)" % B),
@@ -583,7 +591,8 @@ def main():
             del x
             torch.cuda.empty_cache()
             out["sampler_loop"] = sampler_lines(op, y, dev, B)
-        if world == 1 and a.task == "mri" and a.coils == 0 and a.batch is None and not a.no_small_batches:
+        if world == 1 and a.task == "mri" and a.coils == 0 and a.batch is None and not a.no_small_batches \
+                and a.resolution == 192:
             # the batches a GPU really sees: the reference runs B = 1 (sample.py:64-65) and config 5
             # on 8 GPUs is 32 / 8 = 4 chains per GPU (frames shared between workgroups there)
             del x
@@ -593,7 +602,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             if a.task == "blackhole":
                 out["cpu_baseline"] = cpu_baseline_blackhole(tab, a.cpu_reps)
-            elif a.task == "mri" and a.coils == 0:
+            elif a.task == "mri" and a.coils == 0 and a.resolution == 192:
                 out["cpu_baseline"] = cpu_baseline_mri(a.cpu_reps * 4)
         print(json.dumps(out))
     if dist is not None:

@@ -177,10 +177,18 @@ class DynamicMRI(Operator):
         grad = torch.empty_like(x) if need_grad else None
         if self._generic(x):
             ws = self._any_ws(x)
+            t0 = None
+            if self._prof is not None:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(torch.cuda.current_stream(x.device))
             rc = _lib.lib().mri_loss_grad_any(x.data_ptr(), y.data_ptr(), y.shape[0], B, T, x.shape[3], x.shape[4],
                                               rows.data_ptr(), nrows.data_ptr(), self.mask.shape[1], self._max_rows,
                                               _lib.ptr(chain_scale), ws.data_ptr(), ws.numel(), loss.data_ptr(),
                                               loss.data_ptr() + 4 * B, _lib.ptr(grad), _lib.stream_of(x))
+            if t0 is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(torch.cuda.current_stream(x.device))
+                self._prof.setdefault("mri_loss_grad", []).append((t0, t1))
             _lib.check(rc, "mri_loss_grad_any")
             self._loss_total = loss[B]
             return loss[:B], grad
