@@ -5,11 +5,17 @@
 #include "common.h"
 #include "fft_any.h"
 
+#ifndef ANY_THREADS
 #define ANY_THREADS 512
-#define ANY_LDS_BUF (64 * 1024)       // line buffer(s) of a workgroup: two workgroups per CU, three below 52 KB
+#endif
+#ifndef ANY_LDS_BUF
+#define ANY_LDS_BUF (64 * 1024)
+#endif
+// (line buffer(s) of a workgroup: two workgroups per CU at 64 KB, three below 52 KB)
 
 static size_t any_lds_bytes(int n, int ld, int nl, int direct) {
-    return ((size_t)n + (size_t)(direct ? 2 : 1) * n * ld + nl) * sizeof(cf32) + 16 * sizeof(float);
+    return ((size_t)n + (size_t)(direct ? 2 : 1) * n * ld + nl) * sizeof(cf32) + 16 * sizeof(float) +
+           (size_t)((nl + 1) & ~1) * sizeof(int);
 }
 
 __device__ __forceinline__ void any_twiddles(cf32* tw, int n) {

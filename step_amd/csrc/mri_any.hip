@@ -37,18 +37,18 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_cols_fwd(
     const float* xr = x + (size_t)frame * 2 * H * W;
     const float* xi = xr + (size_t)H * W;
     any_twiddles(tw, H);
-    // eight pixels per thread in flight at a time (a plain loop waits for every load before the next)
-    for (int e0 = tid; e0 < H * SW; e0 += 8 * ANY_THREADS) {
-        cf32 v[8];
+    // twelve pixels per thread in flight at a time (a plain loop waits for every load before the next)
+    for (int e0 = tid; e0 < H * SW; e0 += 12 * ANY_THREADS) {
+        cf32 v[12];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 12; ++u) {
             const int e = e0 + u * ANY_THREADS, i = e >> lgSW, c = e & (SW - 1);
             const bool ok = e < H * SW && c < nl;
             const size_t o = ok ? (size_t)i * W + c0 + c : 0;
             v[u] = c_make(xr[o], xi[o]);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 12; ++u) {
             const int e = e0 + u * ANY_THREADS;
             if (e < H * SW) a[e] = v[u];
         }
@@ -58,12 +58,20 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_cols_fwd(
     const int nk = nrows[mf];
     const int* rowl = rows + (size_t)mf * H;
     cf32* dst = ws + (size_t)frame * max_rows * W + c0;
-    for (int e = tid; e < nk * SW; e += ANY_THREADS) {
-        const int j = e >> lgSW, c = e & (SW - 1);
-        if (c < nl) {
-            const int ky = rowl[j];
-            const cf32 w = tw[any_shift_idx(ky, H)];
-            dst[(size_t)j * W + c] = c_rot<-1>(a[ky * SW + c], w.x, w.y);
+    for (int e0 = tid; e0 < nk * SW; e0 += 4 * ANY_THREADS) {     // the row list four entries ahead of their use
+        int ky[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * ANY_THREADS;
+            ky[u] = e < nk * SW ? rowl[e >> lgSW] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * ANY_THREADS, j = e >> lgSW, c = e & (SW - 1);
+            if (e < nk * SW && c < nl) {
+                const cf32 w = tw[any_shift_idx(ky[u], H)];
+                dst[(size_t)j * W + c] = c_rot<-1>(a[ky[u] * SW + c], w.x, w.y);
+            }
         }
     }
 }
@@ -81,7 +89,8 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_rows(
     cf32* tw = (cf32*)lds;
     cf32* phr = tw + W;                               // [NR] fftshift phase of each row of the group
     float* red = (float*)(phr + NR);
-    cf32* a = (cf32*)(red + 16);
+    int* rl = (int*)(red + 16);                       // [NR] the group's k_y rows (a copy of the global list)
+    cf32* a = (cf32*)(rl + ((NR + 1) & ~1));
     cf32* b = a + (size_t)W * LD;                     // only with a direct pass in the plan
     const int frame = blockIdx.x / ngroups, grp = blockIdx.x - frame * ngroups, tid = threadIdx.x;
     const int bch = frame / T, t = frame - bch * T;
@@ -96,10 +105,12 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_rows(
     cf32* wrow = ws + ((size_t)frame * max_rows + j0) * W;
     any_twiddles(tw, W);
     if (tid < nr) {
+        const int ky = rowl[tid];
         float sn, cn;
-        sincospif((float)(2 * any_shift_idx(rowl[tid], H)) / (float)H, &sn, &cn);
+        sincospif((float)(2 * any_shift_idx(ky, H)) / (float)H, &sn, &cn);
         phr[tid] = c_make(cn, sn);
-    }
+        rl[tid] = ky;                                 // from LDS below: a global load of the row id ahead of every
+    }                                                 // measurement load was a second memory latency per batch
     __syncthreads();
     const size_t plane = (size_t)H * W;
     if (MODE == 2) {
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_rows(
         const float* gi = gr + plane;
         for (int e = tid; e < nr * W; e += ANY_THREADS) {
             const int jj = e / W, kx = e - jj * W;
-            const size_t o = (size_t)rowl[jj] * W + kx;
+            const size_t o = (size_t)rl[jj] * W + kx;
             const cf32 wx = tw[any_shift_idx(kx, W)], wy = phr[jj];
             cf32 v = c_rot<1>(c_make(gr[o], gi[o]), wx.x, wx.y);
             a[kx * LD + jj] = c_rot<1>(v, wy.x, wy.y);
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_rows(
             const int jj = e / W, kx = e - jj * W;
             const cf32 wx = tw[any_shift_idx(kx, W)];
             const cf32 v = c_rot<-1>(a[kx * LD + jj], wx.x, wx.y);
-            const size_t o = (size_t)rowl[jj] * W + kx;
+            const size_t o = (size_t)rl[jj] * W + kx;
             outr[o] = v.x;
             outi[o] = v.y;
         }
@@ -153,16 +164,16 @@ __global__ __launch_bounds__(ANY_THREADS, 4) void k_any_rows(
     const float* yi = yr + plane;
     const float cs2 = 2.f * (chain_scale ? chain_scale[bch] : 1.f);
     float acc = 0.f;
-    for (int e0 = tid; e0 < nr * W; e0 += 4 * ANY_THREADS) {
-        cf32 ym[4];
+    for (int e0 = tid; e0 < nr * W; e0 += 8 * ANY_THREADS) {
+        cf32 ym[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * ANY_THREADS, ec = e < nr * W ? e : 0, jj = ec / W, kx = ec - jj * W;
-            const size_t o = (size_t)rowl[jj] * W + kx;
+            const size_t o = (size_t)rl[jj] * W + kx;
             ym[u] = c_make(yr[o], yi[o]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * ANY_THREADS, jj = e / W, kx = e - jj * W;
             if (e < nr * W) {
                 const cf32 wx = tw[any_shift_idx(kx, W)], wy = phr[jj];
