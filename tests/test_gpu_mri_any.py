@@ -3,9 +3,10 @@ mri_loss_grad_any through the C ABI) behind the reference's `resolution` argumen
 (forward_operator/dynamic_mri.py:9,42-48; loss / gradient base.py:40-49).
 
 Pinning: at 192 x 192 the same kernels are held against the golden fixtures written from the reference
-(tests/golden/mri_*.npz) and against the tuned kernels; at every other size against oracle/mri_oracle.py, the
-restatement those fixtures pin (the reference holds no fixture at another resolution; its operator is the same
-three torch calls at any size)."""
+(tests/golden/mri_*.npz) and against the tuned kernels; at 128, 160, 75, 97 and 256 against
+tests/golden/mri_sizes.npz, written from the reference's own operator at those resolutions
+(oracle/gen_golden_mri_sizes.py); at the other sizes against oracle/mri_oracle.py, the restatement all of
+these fixtures pin."""
 import numpy as np
 import pytest
 import torch
@@ -169,3 +170,27 @@ def test_awkward_sizes(res, dev):
     assert_close(l_got, l_ref, RTOL, "loss")
     assert_close(g_got, g_ref, RTOL, "gradient")
     assert_close(op(x.to(dev)), orc(x), RTOL, "forward")
+
+
+def test_other_resolutions_match_the_reference_fixtures(golden, dev):
+    """tests/golden/mri_sizes.npz: outputs of the REFERENCE's DynamicMRI at 128, 160, 75 (odd), 97 (prime) and 256,
+    written by oracle/gen_golden_mri_sizes.py -- the any-size kernels against the reference itself, not only
+    against the oracle."""
+    from step_amd.forward_operator import get_operator
+    from tests.test_oracle_golden import mri_size_cases, mri_size_inputs
+    g = golden("mri_sizes")
+    for i, res, mode, acc, acs, fr, B, noise in mri_size_cases(g):
+        op = get_operator("mri", acc_factor=acc, mode=mode, resolution=res, frames=fr, num_acs_lines=acs, sigma=noise)
+        k = "c%d_" % i
+        assert np.array_equal(op.mask[0, :, 0, :, 0].numpy().astype(np.uint8), g[k + "mask"])
+        x_gt, x, nz = mri_size_inputs(res, fr, B)
+        y = op(x_gt.to(dev)) + noise * nz.to(dev)
+        fwd = op(x.to(dev))
+        assert (fwd.cpu().flatten()[::7] - t(g[k + "fwd_sub"])).abs().max().item() <= RTOL * float(np.abs(g[k + "fwd_sub"]).max())
+        assert_close(fwd[0, 0], g[k + "fwd_frame0"], RTOL, "forward frame 0 at %d" % res)
+        grad, lsum = op.gradient(x.to(dev), y, return_loss=True)
+        assert (grad.cpu().flatten()[::7] - t(g[k + "grad_sub"])).abs().max().item() <= RTOL * float(np.abs(g[k + "grad_sub"]).max())
+        assert_close(grad[0, 0], g[k + "grad_frame0"], RTOL, "gradient frame 0 at %d" % res)
+        assert_close((grad.double() ** 2).flatten(1).sum(-1), g[k + "grad_sq_sum"], RTOL, "gradient energy at %d" % res)
+        assert_close(lsum, g[k + "loss_sum"], RTOL, "loss sum at %d" % res)
+        assert_close(op.loss(x.to(dev), y), g[k + "loss"], RTOL, "loss at %d" % res)

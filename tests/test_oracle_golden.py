@@ -72,6 +72,36 @@ def test_mri_oracle_matches_reference_outputs(mode, golden):
     close(orc.loss(x, y), g["loss"], 1e-5)
 
 
+def mri_size_cases(g):
+    """(index, resolution, mode, acc, acs, frames, B, noise) of tests/golden/mri_sizes.npz (written from the
+    reference by oracle/gen_golden_mri_sizes.py)."""
+    return [(i, int(c[0]), str(g["modes"][i]), int(c[1]), int(c[2]), int(c[3]), int(c[4]), float(g["noise"][i]))
+            for i, c in enumerate(g["cases"])]
+
+
+def mri_size_inputs(res, frames, B):
+    rng = np.random.RandomState(1000 + res)
+    shape = (B, frames, 2, res, res)
+    return tuple(torch.from_numpy(rng.randn(*shape).astype(np.float32)) for _ in range(3))
+
+
+def test_mri_oracle_matches_reference_outputs_at_other_resolutions(golden):
+    g = golden("mri_sizes")
+    for i, res, mode, acc, acs, fr, B, noise in mri_size_cases(g):
+        orc = MRIOracle(acc, mode, res, fr, acs, sigma=noise)
+        k = "c%d_" % i
+        assert np.array_equal(orc.mask[0, :, 0, :, 0].numpy().astype(np.uint8), g[k + "mask"])
+        x_gt, x, nz = mri_size_inputs(res, fr, B)
+        y = orc(x_gt) + noise * nz
+        fwd = orc(x)
+        close(fwd.flatten()[::7], g[k + "fwd_sub"], 1e-5)
+        close(fwd[0, 0], g[k + "fwd_frame0"], 1e-5)
+        grad, lsum = orc.gradient(x, y, return_loss=True)
+        close(grad.flatten()[::7], g[k + "grad_sub"], 1e-5)
+        close(lsum, g[k + "loss_sum"], 1e-5)
+        close(orc.loss(x, y), g[k + "loss"], 1e-5)
+
+
 def test_mri_masks_all_configs(golden):
     from oracle.mri_oracle import build_mask
     d = golden("mri_masks")
