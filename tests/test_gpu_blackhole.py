@@ -354,6 +354,39 @@ def test_full_size_well_conditioned_meets_1e4_outright(dft, golden, dev):
     assert abs(gc.abs().sum().item() - float(g["x_grad_abs_sum"])) <= RTOL * float(g["x_grad_abs_sum"])
 
 
+@pytest.mark.parametrize("n,dft", [(64, "sep3"), (128, "sep3"), (64, "sep"), (96, "sep"), (160, "sep"), (96, "dense")])
+def test_other_image_sizes_against_reference_fixtures(n, dft, golden, dev):
+    """tests/golden/bh_sizes.npz (oracle/gen_golden_bh_sizes.py): the reference's own fp32 outputs at 64 x N x N
+    for N = 64, 128 (the folded kernels' other instantiations) and 96, 160 (fp32 separable kernels only), 6
+    stations, well-conditioned ring videos -- the 1e-4 bar asserted plainly on every field, loss and gradient."""
+    from step_amd import eht_lite
+    from step_amd.forward_operator import BlackHoleImagingTorch, BlackHoleObservation
+    g = golden("bh_sizes")
+    tag = "n%d" % n
+    assert float(g[tag + "_cond_min_ratio"]) >= 1e-3
+    tab = eht_lite.synthetic_table(int(g["n_sites"]), 64, seed=int(g["obs_seed"]), sigma_scale=float(g[tag + "_sigma_scale"]))
+    assert np.array_equal(tab["uv"], g[tag + "_uv"])
+    op = BlackHoleImagingTorch(imsize=n, ref_multiplier=0.001, device=dev, obs_table=tab, dft=dft, **weights_kw(g))
+    assert op.path == dft
+    assert torch.equal(op.cp_index.cpu(), t(g[tag + "_cp_index"])) and torch.equal(op.camp_index.cpu(), t(g[tag + "_camp_index"]))
+    x = torch.from_numpy(eht_synth.ring_video(400 + n, n=n))
+    assert float(x.double().sum()) == float(g[tag + "_x_checksum"])
+    y = BlackHoleObservation(*obs_from_golden(g, tag + "_y_", dev))
+    o = op(x.to(dev))
+    for name, got, want in zip(Obs._fields, o.to_list(), obs_from_golden(g, tag + "_obs_")):
+        if name == "cphase":
+            assert angle_err(got, want) <= RTOL, "cphase"
+        else:
+            assert_close(got, want, RTOL, "obs." + name)
+    assert_close(op.loss(x.to(dev), y), g[tag + "_loss"], RTOL, "loss")
+    grad, lsum = op.gradient(x.to(dev), y, return_loss=True)
+    assert_close(lsum, g[tag + "_loss_sum"], RTOL, "loss sum")
+    gc = grad.cpu()
+    assert_close(gc.flatten()[::97], g[tag + "_grad_sub"], RTOL, "gradient (every 97th pixel)")
+    assert_close(gc.flatten(2).sum(-1), g[tag + "_grad_frame_sum"], RTOL, "per-frame gradient sums")
+    assert abs(gc.abs().sum().item() - float(g[tag + "_grad_abs_sum"])) <= RTOL * float(g[tag + "_grad_abs_sum"])
+
+
 def test_full_size_error_distribution_per_path(golden, dev, capsys):
     """The ill-conditioned family (uniform random pixels: one nearly vanishing visibility sets the
     gradient's max-norm) over four seeds: each path's error against the fp64 evaluation of the

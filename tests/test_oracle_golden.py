@@ -4,10 +4,10 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.bh_oracle import Obs, closure_tables
+from oracle.bh_oracle import BlackholeOracle, Obs, closure_tables
 from oracle.mcmc_oracle import LatentWrapOracle, MCMCOracle, edm_sigmas, lr_at
 from oracle.mri_oracle import MRIOracle
-from tests.helpers import obs_from_golden, oracle_from_golden, t
+from tests.helpers import obs_from_golden, oracle_from_golden, t, weights_kw
 from tests.toy_model import ToyModel
 
 TIGHT = 2e-6      # same formulas, same dtype: only BLAS/vectorisation differences between CPUs
@@ -187,3 +187,28 @@ def test_multicoil_oracle_reduces_to_the_pinned_single_coil_oracle():
     m2 = MultiCoilMRIOracle(6, "same_mask", 192, 12, 24, s2)
     want = sc.loss(x, y) + (sc(2 * torch.stack([-x[:, :, 1], x[:, :, 0]], 2)) - y).pow(2).flatten(1).sum(-1)
     close(m2.loss(x, torch.stack([y, y], 2)), want, 1e-6)
+
+
+def test_blackhole_oracle_matches_reference_outputs_at_another_image_size(golden):
+    """tests/golden/bh_sizes.npz, N = 64: the oracle rebuilt from the fixture's uv table reproduces the reference's
+    observation, loss and gradient (the generator compared all four sizes bit for bit when it wrote the file)."""
+    from oracle import eht_synth
+    from oracle.bh_oracle import closure_tables
+    g = golden("bh_sizes")
+    n, tag = 64, "n64"
+    syn = eht_synth.synthetic_obs(int(g["n_sites"]), 64, seed=int(g["obs_seed"]), sigma_scale=float(g[tag + "_sigma_scale"]))
+    assert np.array_equal(syn["uv"], g[tag + "_uv"])
+    A = np.stack([eht_synth.ftmatrix_dense(eht_synth.PSIZE, n, n, syn["uv"][i]) for i in range(64)])
+    cpi, cpc, cai, cac = closure_tables(syn["times"], syn["t1"], syn["t2"], syn["tri"], syn["quad"])
+    assert np.array_equal(np.asarray(cpi), g[tag + "_cp_index"]) and np.array_equal(np.asarray(cai), g[tag + "_camp_index"])
+    orc = BlackholeOracle(torch.from_numpy(A).to(torch.complex64).unsqueeze(0), torch.from_numpy(syn["sigma"]).float() / 0.001,
+                          torch.tensor(cpi), torch.tensor(cpc), torch.tensor(cai), torch.tensor(cac), 64, n, n,
+                          **weights_kw(g))
+    x = torch.from_numpy(eht_synth.ring_video(400 + n, n=n))
+    assert float(x.double().sum()) == float(g[tag + "_x_checksum"])
+    y = obs_from_golden(g, tag + "_y_")
+    for name, got, want in zip(Obs._fields, orc(x), obs_from_golden(g, tag + "_obs_")):
+        close(got, want, 1e-5)
+    grad, lsum = orc.gradient(x, y, return_loss=True)
+    close(lsum, g[tag + "_loss_sum"], 1e-5)
+    close(grad.flatten()[::97], g[tag + "_grad_sub"], 1e-4)
