@@ -193,6 +193,23 @@ def cpu_baseline_mri(reps):
     return out
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: RCCL prints its version banner on stdout when its
+    first communicator comes up, and rank 0's stdout is to carry ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def timed_region(step, steps, sync, barrier, reduce_max, gather):
     """The contract's timed region, shared by the GPU run and --dry-run: barrier + sync, exactly
     `steps` calls of `step`, sync, this rank's clock stops, barrier.  The rank's time is taken BEFORE
@@ -387,6 +404,7 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world)
     dist = side = None
+    gloo_fallback = False
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:     # launched by torch.distributed.run
         import torch.distributed as dist
         if a.rehearse_on_one_gpu:
@@ -394,8 +412,36 @@ def main():
             dist.init_process_group("gloo")
             local = local % max(1, torch.cuda.device_count())
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        if a.barrier == "gloo" and not a.rehearse_on_one_gpu:
+            # RCCL carries nothing of the workload (chains are independent: no data-path collective), only the
+            # bracket barriers and one float per rank.  If it cannot come up on this node (IPC, fabric), say so
+            # and run the same bench with those few bytes on gloo instead of failing the whole measurement.
+            import datetime
+            if local >= torch.cuda.device_count():
+                raise SystemExit("bench.py: rank %d wants cuda:%d but %d device(s) are visible (one rank per GPU; "
+                                 "--rehearse-on-one-gpu shares a card)" % (rank, local, torch.cuda.device_count()))
+            try:
+                torch.cuda.set_device(local)
+                with stdout_to_stderr():
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                            timeout=datetime.timedelta(seconds=120))
+                    probe = torch.ones(1, device=torch.device("cuda", local))
+                    dist.all_reduce(probe)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce of ones gave %r on %d ranks" % (probe.item(), world))
+            except Exception as e:
+                print("bench.py: RCCL did not come up on rank %d (%s: %s); process group on gloo" %
+                      (rank, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else ""), file=sys.stderr)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:
+                    pass
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+                gloo_fallback = True
+        if a.barrier == "gloo" and not a.rehearse_on_one_gpu and not gloo_fallback:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the ranks meet on the loopback
             try:
                 side = dist.new_group(backend="gloo")
@@ -442,7 +488,7 @@ def main():
         x = torch.randn(B, 12, 2, R, R, device=dev, generator=gen)
         y = op(torch.randn(1, 12, 2, R, R, device=dev, generator=gen))
 
-    comm = Comm(dist, side, torch.device("cpu") if a.rehearse_on_one_gpu else dev, world)
+    comm = Comm(dist, side, torch.device("cpu") if (a.rehearse_on_one_gpu or gloo_fallback) else dev, world)
 
     def barrier():
         if dist is not None:
@@ -571,7 +617,9 @@ def main():
                    per_rank_ms_per_step=[1e3 * v / a.steps for v in per_rank],
                    bracket_barrier=("none (one process)" if dist is None else
                                     "gloo (rehearsal: all ranks on one card, NOT a scaling measurement)"
-                                    if a.rehearse_on_one_gpu else "gloo (host)" if side is not None else "rccl"),
+                                    if a.rehearse_on_one_gpu else
+                                    "gloo (RCCL did not come up on this node: see stderr)" if gloo_fallback else
+                                    "gloo (host)" if side is not None else "rccl"),
                    config=dict(workload=workload, chains_per_gpu=B, path=getattr(op, "path", "fused"),
                                parallelism="independent chains, %d per GPU" % B),
                    roofline=roof)
